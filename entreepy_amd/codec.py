@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference's codec interface over the C ABI.
+
+    reference                                   here
+    encode(allocator, text, out_writer,         encode(text, flags) -> bytes
+           std_out, flags) !usize  (encode.zig:25)
+    decode(allocator, compressed_text, ...)     decode(compressed_text, flags) -> bytes
+           !usize                   (decode.zig:13)
+    EncodeFlags / DecodeFlags (encode.zig:9-14, decode.zig:7-11)
+    error.QueueEmpty on empty input             EmptyInputError
+
+`compressed_text` keeps the reference's convention: the .et file minus its first four
+bytes (main.zig:204, test.zig:26).  Everything numeric happens in libentreepy_hip.so;
+torch appears only as the owner of device memory and streams in the *_device calls.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+
+class EntreepyError(RuntimeError):
+    def __init__(self, status, detail=""):
+        msg = N.lib().et_strerror(status).decode()
+        super().__init__(f"{msg}{': ' + detail if detail else ''} (et_status {status})")
+        self.status = status
+
+
+class EmptyInputError(EntreepyError):
+    """The reference's error.QueueEmpty (queue.zig:28-30 reached from encode.zig:137-138)."""
+
+
+@dataclass
+class EncodeFlags:  # encode.zig:9-14
+    write_output: bool = False
+    print_output: bool = False
+    debug: bool = False
+
+
+@dataclass
+class DecodeFlags:  # decode.zig:7-11
+    write_output: bool = False
+    print_output: bool = False
+    debug: bool = False
+
+
+def _check(status, ctx=None):
+    if status == N.ET_OK:
+        return
+    detail = N.lib().et_last_error(ctx).decode() if ctx else ""
+    if status == N.ET_ERR_EMPTY:
+        raise EmptyInputError(status, detail)
+    raise EntreepyError(status, detail)
+
+
+def _host_u8(buf):
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+    return a, (a.ctypes.data if a.size else None)
+
+
+class Codebook:
+    """The code table (reference `dictionary`), host side."""
+
+    def __init__(self, raw=None):
+        self.raw = raw if raw is not None else N.Codebook()
+
+    @classmethod
+    def from_histogram(cls, hist):
+        """encode.zig:54-214 via et_build_codebook."""
+        h = np.ascontiguousarray(hist, dtype=np.uint64)
+        assert h.size == 256
+        cb = cls()
+        _check(N.lib().et_build_codebook(h.ctypes.data, ctypes.byref(cb.raw)))
+        return cb
+
+    @classmethod
+    def from_tables(cls, data, length):
+        """An arbitrary table (tests of the long-code path)."""
+        cb = cls()
+        d = np.ascontiguousarray(data, dtype=np.uint32)
+        l = np.ascontiguousarray(length, dtype=np.uint8)
+        ctypes.memmove(cb.raw.data, d.ctypes.data, 1024)
+        ctypes.memmove(cb.raw.length, l.ctypes.data, 256)
+        nz = l[l > 0]
+        cb.raw.n_coded = int(nz.size)
+        cb.raw.min_length = int(nz.min()) if nz.size else 0
+        cb.raw.max_length = int(nz.max()) if nz.size else 0
+        return cb
+
+    @property
+    def data(self):
+        return np.frombuffer(self.raw.data, dtype=np.uint32).copy()
+
+    @property
+    def length(self):
+        return np.frombuffer(self.raw.length, dtype=np.uint8).copy()
+
+    @property
+    def dfs_order(self):
+        # a lone symbol is a leaf-root with length 0 (encode.zig:137-138): still one dump line
+        n = int(self.raw.n_coded) or 1
+        return np.frombuffer(self.raw.dfs_order, dtype=np.uint8)[:n].copy()
+
+    def header(self, text_len):
+        """encode.zig:259-299 via et_write_header."""
+        out = np.zeros(8192, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        _check(N.lib().et_write_header(ctypes.byref(self.raw), int(text_len), out.ctypes.data, out.size, ctypes.byref(n)))
+        return out[: n.value].tobytes()
+
+    def bits(self, hist):
+        h = np.ascontiguousarray(hist, dtype=np.uint64)
+        b = ctypes.c_uint64(0)
+        _check(N.lib().et_codebook_bits(ctypes.byref(self.raw), h.ctypes.data, ctypes.byref(b)))
+        return b.value
+
+
+def parse_header(compressed_text):
+    """decode.zig:34-141 via et_parse_header -> (Codebook, n_symbols, body_offset)."""
+    a, p = _host_u8(compressed_text)
+    cb = Codebook()
+    n = ctypes.c_uint64(0)
+    off = ctypes.c_size_t(0)
+    _check(N.lib().et_parse_header(p, a.size, ctypes.byref(cb.raw), ctypes.byref(n), ctypes.byref(off)))
+    return cb, n.value, off.value
+
+
+def encode_bound(n):
+    return N.lib().et_encode_bound(n)
+
+
+class Context:
+    """One et_ctx: a GPU's stream, workspaces and pinned staging."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        self.device = device
+        _check(N.lib().et_ctx_create(device, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            N.lib().et_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- plumbing ---------------------------------------------------------------
+    def use_stream(self, hip_stream):
+        """Run on a caller-owned stream, e.g. torch.cuda.current_stream().cuda_stream."""
+        _check(N.lib().et_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream) if hip_stream else None), self._h)
+
+    def use_torch_stream(self):
+        import torch
+
+        self.use_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reserve(self, max_text_bytes):
+        _check(N.lib().et_ctx_reserve(self._h, int(max_text_bytes)), self._h)
+
+    def enable_timing(self, on=True):
+        _check(N.lib().et_ctx_enable_timing(self._h, int(bool(on))), self._h)
+
+    def timings(self):
+        t = N.Timings()
+        _check(N.lib().et_last_timings(self._h, ctypes.byref(t)), self._h)
+        return {k: getattr(t, k) for k, _ in N.Timings._fields_ if k != "reserved"}
+
+    # -- whole calls, host memory --------------------------------------------------
+    def encode(self, text):
+        a, p = _host_u8(text)
+        out = np.empty(encode_bound(a.size), dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        _check(N.lib().et_encode(self._h, p, a.size, out.ctypes.data, out.size, ctypes.byref(n)), self._h)
+        return out[: n.value].tobytes()
+
+    def decode(self, compressed_text):
+        a, p = _host_u8(compressed_text)
+        want = ctypes.c_size_t(0)
+        _check(N.lib().et_decoded_size(p, a.size, ctypes.byref(want)), self._h)
+        out = np.empty(want.value + 64, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        _check(N.lib().et_decode(self._h, p, a.size, out.ctypes.data, out.size, ctypes.byref(n)), self._h)
+        return out[: n.value].tobytes()
+
+    # -- whole calls, device memory (torch uint8 tensors) ------------------------------
+    def encode_device(self, text, out):
+        """text, out: 1-D uint8 CUDA tensors; out.numel() >= encode_bound(text.numel()).
+        Stream-ordered: returns the .et byte count without waiting for the kernels."""
+        n = ctypes.c_size_t(0)
+        _check(N.lib().et_encode_device(self._h, text.data_ptr(), text.numel(), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
+        return n.value
+
+    def decode_device(self, compressed_text, out):
+        n = ctypes.c_size_t(0)
+        _check(N.lib().et_decode_device(self._h, compressed_text.data_ptr(), compressed_text.numel(), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
+        return n.value
+
+    # -- staged calls (sharded encode) ----------------------------------------------
+    def histogram_device(self, text, hist):
+        """text: uint8 CUDA tensor; hist: int64/uint64 CUDA tensor of 256 counters."""
+        assert hist.numel() == 256 and hist.element_size() == 8
+        _check(N.lib().et_histogram_device(self._h, text.data_ptr(), text.numel(), hist.data_ptr()), self._h)
+
+    def encode_body_device(self, codebook, text, out, start_bit=0):
+        end = ctypes.c_uint64(0)
+        _check(N.lib().et_encode_body_device(self._h, ctypes.byref(codebook.raw), text.data_ptr(), text.numel(), out.data_ptr(),
+                                             out.numel() * out.element_size(), int(start_bit), ctypes.byref(end)), self._h)
+        return end.value
+
+    def decode_body_device(self, codebook, body, n_symbols, out, start_bit=0):
+        n = ctypes.c_size_t(0)
+        _check(N.lib().et_decode_body_device(self._h, ctypes.byref(codebook.raw), body.data_ptr(), body.numel(), int(start_bit),
+                                             int(n_symbols), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
+        return n.value
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def encode(text, flags=None, device=0):
+    """encode.zig:25.  Returns the .et file image (the bytes the reference hands to
+    out_writer.writeAll, encode.zig:319).  Raises EmptyInputError on b''."""
+    return default_context(device).encode(text)
+
+
+def decode(compressed_text, flags=None, device=0):
+    """decode.zig:13.  `compressed_text` = .et file minus its first 4 bytes."""
+    return default_context(device).decode(compressed_text)

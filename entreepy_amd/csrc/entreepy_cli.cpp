@@ -1,0 +1,216 @@
+// entreepy_cli.cpp -- the `entreepy` command: same surface as the reference's
+// src/main.zig (options -h -p -t -d, commands c/d, -o), with encode()/decode()
+// replaced by libentreepy_hip.so.  The reference's host is Zig; no Zig toolchain
+// exists in this image, so the tested host driver is C++ (INTEGRATION.md has the Zig
+// shim a maintainer would use instead).
+#include "entreepy_hip.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+// main.zig:45-67, verbatim.
+const char kHelp[] =
+    "Entreepy - Text compression tool\n"
+    "\n"
+    "Usage: entreepy [options] [command] [file] [command options]\n"
+    "\n"
+    "Options:\n"
+    "    -h, --help     show help\n"
+    "    -p, --print    print decompressed text to stdout\n"
+    "    -t, --test     test/dry run, does not write to file\n"
+    "    -d, --debug    print huffman code dictionary and performance times to stdout\n"
+    "\n"
+    "Commands:\n"
+    "    c    compress a file\n"
+    "    d    decompress a file\n"
+    "\n"
+    "Command Options:\n"
+    "    -o, --output    output file (default: [file].et or decoded_[file])\n"
+    "\n"
+    "Examples:\n"
+    "    entreepy -d c text.txt -o text.txt.et\n"
+    "    entreepy -ptd d text.txt.et -o decoded_text.txt\n";
+
+enum class Mode { None, Compress, Decompress };
+
+struct Options {
+    bool print = false, debug = false, dry = false;
+    Mode mode = Mode::None;
+    std::string in_path, out_path;
+    bool have_in = false;
+};
+
+// utils.zig:3-13: f32 byte count, 1024 divisors, two decimals above 1 KiB.
+std::string format_file_size(float byte_count) {
+    char buf[64];
+    if (byte_count < 1024.0f) std::snprintf(buf, sizeof buf, "%g B", static_cast<double>(byte_count));
+    else if (byte_count < 1024.0f * 1024.0f) std::snprintf(buf, sizeof buf, "%.2f KB", static_cast<double>(byte_count / 1024.0f));
+    else if (byte_count < 1024.0f * 1024.0f * 1024.0f) std::snprintf(buf, sizeof buf, "%.2f MB", static_cast<double>(byte_count / (1024.0f * 1024.0f)));
+    else std::snprintf(buf, sizeof buf, "%.2f GB", static_cast<double>(byte_count / (1024.0f * 1024.0f * 1024.0f)));
+    return buf;
+}
+
+// main.zig:73-146.  Returns 0 to continue, 1 to exit successfully (help), 2 on error.
+int parse_cli(int argc, char **argv, Options &o) {
+    enum { Normal, OutPath, InPath } state = Normal;
+    if (argc <= 1) {  // main.zig:148-152
+        std::fputs(kHelp, stdout);
+        return 1;
+    }
+    for (int i = 1; i < argc; ++i) {
+        const std::string arg = argv[i];
+        switch (state) {
+            case Normal:
+                if (!arg.empty() && arg[0] == '-') {
+                    bool stop = false;
+                    for (size_t k = 1; k < arg.size() && !stop; ++k) {
+                        switch (arg[k]) {
+                            case 'h': std::fputs(kHelp, stdout); return 1;
+                            case 'p': o.print = true; break;
+                            case 'd': o.debug = true; break;
+                            case 't': o.dry = true; break;
+                            case 'o': state = OutPath; break;
+                            case '-': {
+                                const std::string name = arg.substr(2);
+                                if (name == "help") { std::fputs(kHelp, stdout); return 1; }
+                                else if (name == "print") o.print = true;
+                                else if (name == "debug") o.debug = true;
+                                else if (name == "test") o.dry = true;
+                                else if (name == "output") state = OutPath;
+                                else { std::fprintf(stderr, "error: invalid option: %s\n\n", arg.c_str()); return 2; }
+                                stop = true;
+                                break;
+                            }
+                            default: std::fprintf(stderr, "error: invalid option: %s\n\n", arg.c_str()); return 2;
+                        }
+                    }
+                } else if (!arg.empty() && (arg[0] == 'c' || arg[0] == 'd')) {  // main.zig:123-130
+                    o.mode = arg[0] == 'c' ? Mode::Compress : Mode::Decompress;
+                    state = InPath;
+                } else {
+                    std::fprintf(stderr, "error: invalid command: %s\n\n", arg.c_str());
+                    return 2;
+                }
+                break;
+            case InPath: o.in_path = arg; o.have_in = true; state = Normal; break;
+            case OutPath: o.out_path = arg; state = Normal; break;
+        }
+    }
+    if (o.mode == Mode::None) return 1;
+    if (!o.have_in) { std::fprintf(stderr, "error: no input file\n"); return 2; }
+    // main.zig:154-170 (the intended defaults; the reference reads an undefined slice here)
+    if (o.out_path.empty()) {
+        if (o.mode == Mode::Compress) {
+            o.out_path = o.in_path + ".et";
+        } else {
+            const size_t slash = o.in_path.find_last_of('/');
+            const std::string dir = slash == std::string::npos ? "" : o.in_path.substr(0, slash);
+            std::string name = slash == std::string::npos ? o.in_path : o.in_path.substr(slash + 1);
+            if (name.size() >= 3 && name.compare(name.size() - 3, 3, ".et") == 0) name.resize(name.size() - 3);
+            o.out_path = (dir.empty() ? "" : dir + "/") + "decoded_" + name;
+        }
+    }
+    return 0;
+}
+
+bool read_file(const std::string &path, std::vector<uint8_t> &data) {  // main.zig:34-40
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) return false;
+    const std::streamsize n = f.tellg();
+    f.seekg(0);
+    data.resize(static_cast<size_t>(n));
+    return n == 0 || static_cast<bool>(f.read(reinterpret_cast<char *>(data.data()), n));
+}
+
+void dump_dictionary(const et_codebook &cb) {  // encode.zig:204-212
+    const unsigned leaves = cb.n_coded ? cb.n_coded : 1;
+    for (unsigned i = 0; i < leaves; ++i) {
+        const unsigned s = cb.dfs_order[i];
+        std::printf("%c %u - ", static_cast<int>(s), s);
+        for (unsigned j = cb.length[s]; j > 0; --j) std::printf("%u", (cb.data[s] >> ((j - 1) & 31u)) & 1u);
+        std::printf("\n");
+    }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Options opt;
+    const int pr = parse_cli(argc, argv, opt);
+    if (pr == 1) return 0;
+    if (pr == 2) return 1;
+
+    std::vector<uint8_t> in;
+    if (!read_file(opt.in_path, in)) {
+        std::fprintf(stderr, "error: FileNotFound: %s\n", opt.in_path.c_str());
+        return 1;
+    }
+    FILE *out_file = nullptr;
+    if (!opt.dry) {  // main.zig:191-197: created (truncated) before coding starts
+        out_file = std::fopen(opt.out_path.c_str(), "wb+");
+        if (!out_file) {
+            std::fprintf(stderr, "error: cannot create %s\n", opt.out_path.c_str());
+            return 1;
+        }
+    }
+
+    et_ctx *ctx = nullptr;
+    int rc = et_ctx_create(0, &ctx);
+    if (rc != ET_OK) {
+        std::fprintf(stderr, "error: %s (no usable MI355X / HIP device; entreepy-hip has no CPU path)\n", et_strerror(rc));
+        return 1;
+    }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t written = 0, reported = 0;
+    std::vector<uint8_t> out;
+    if (opt.mode == Mode::Compress) {
+        out.resize(et_encode_bound(in.size()));
+        rc = et_encode(ctx, in.data(), in.size(), out.data(), out.size(), &written);
+        if (rc == ET_OK) {
+            if (opt.debug) {
+                et_codebook cb;
+                if (et_last_codebook(ctx, &cb) == ET_OK) dump_dictionary(cb);
+            }
+            if (!opt.dry) std::fwrite(out.data(), 1, written, out_file);  // encode.zig:319
+            if (opt.debug) std::printf("\nbits in output: %zu\n", written * 8);  // encode.zig:320
+            reported = written;  // encode.zig:331,336: counts the bytes even with -t
+        }
+    } else {
+        if (in.size() < 9) {
+            rc = ET_ERR_FORMAT;
+        } else {
+            size_t n = 0;
+            et_decoded_size(in.data() + 4, in.size() - 4, &n);
+            out.resize(n + 64);
+            rc = et_decode(ctx, in.data() + 4, in.size() - 4, out.data(), out.size(), &written);  // main.zig:204
+            if (rc == ET_OK) {
+                if (!opt.dry) { std::fwrite(out.data(), 1, written, out_file); reported = written; }  // decode.zig:185-188
+                if (opt.print) std::fwrite(out.data(), 1, written, stdout);                            // decode.zig:189
+            }
+        }
+    }
+    if (rc != ET_OK) {
+        std::fprintf(stderr, "error: %s: %s\n", et_strerror(rc), et_last_error(ctx));
+        et_ctx_destroy(ctx);
+        if (out_file) std::fclose(out_file);
+        return 1;
+    }
+    // encode.zig:334 / decode.zig:217 (decode reports the compressed_text length, i.e. file - 4)
+    const float in_size = static_cast<float>(opt.mode == Mode::Compress ? in.size() : in.size() - 4);
+    std::fprintf(stderr, "%s => %s\n", format_file_size(in_size).c_str(), format_file_size(static_cast<float>(reported)).c_str());
+    if (opt.debug) {  // encode.zig:26-28 / decode.zig:15-17 (deferred to function exit)
+        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("time taken: %lld\xce\xbcs\n", static_cast<long long>(us));
+    }
+    et_ctx_destroy(ctx);
+    if (out_file) std::fclose(out_file);
+    return 0;
+}

@@ -1,0 +1,607 @@
+// et_api.cpp -- the extern "C" boundary of libentreepy_hip.so (include/entreepy_hip.h):
+// context, workspaces, and the orchestration of the kernels in et_kernels.hip.
+//
+// Encode (replaces encode.zig:25-337):
+//   K1 histogram -> D2H 2 KiB -> host code construction (et_codebook.cpp) -> H2D code
+//   table + header -> K2 tile bit totals + scan -> K4 code scatter.
+// Decode (replaces decode.zig:13-220):
+//   D2H header -> host parse + lookup tables -> D1 synchronisation sweeps (until a
+//   sweep reports no change) -> D2 scan of workgroup symbol counts -> D3 write.
+// There is no CPU fallback anywhere in this file: without a usable HIP device every
+// entry point returns ET_ERR_HIP.
+#include "entreepy_hip.h"
+#include "et_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+constexpr size_t HEADER_STAGE = 8192;  // >= 4631-byte worst-case header, padded
+
+}  // namespace
+
+struct et_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    std::string err;
+
+    // encode workspaces
+    DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, len_table;
+    // decode workspaces
+    DevBuf sub_state, blk_exit, blk_count, blk_off, lut, longc, flag;
+    // staging for the host-pointer entry points
+    DevBuf io_in, io_out;
+
+    // pinned host staging
+    uint64_t *h_hist = nullptr;     // 256
+    uint32_t *h_enc = nullptr;      // 512 ({code,len} x 256)
+    uint32_t *h_len = nullptr;      // 256
+    uint8_t *h_header = nullptr;    // HEADER_STAGE
+    uint16_t *h_lut = nullptr;      // 1 << DEC_LUT_BITS_MAX
+    uint32_t *h_long = nullptr;     // 512
+    uint64_t *h_scalar = nullptr;   // 4 (flag / totals)
+
+    // link between et_histogram_device and et_encode_body_device
+    const void *hist_text = nullptr;
+    size_t hist_n = 0;
+    uint32_t hist_rpt = 0, hist_tiles = 0;
+    bool hist_on_host = false;  // h_hist holds the counts of hist_text
+
+    hipEvent_t ev[6] = {};
+    et_timings tm = {};
+    et_codebook last_cb = {};
+    bool have_cb = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int fail(et_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) {
+            ctx->err += ": ";
+            ctx->err += hipGetErrorString(e);
+        }
+    }
+    return status;
+}
+
+#define ET_HIP(call)                                                     \
+    do {                                                                 \
+        hipError_t e_ = (call);                                          \
+        if (e_ != hipSuccess) return fail(ctx, ET_ERR_HIP, #call, e_);   \
+    } while (0)
+
+int ensure(et_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (b.cap >= bytes) return ET_OK;
+    if (b.p) {
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        ET_HIP(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = (bytes + 4095) & ~static_cast<size_t>(4095);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, e == hipErrorOutOfMemory ? ET_ERR_NOMEM : ET_ERR_HIP, "hipMalloc", e);
+    }
+    b.cap = want;
+    return ET_OK;
+}
+
+#define ET_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != ET_OK) return rc_; \
+    } while (0)
+
+// Tile geometry for a stream of `span` bytes measured from the aligned base.
+struct Geometry {
+    const uint8_t *base;
+    uint64_t lo, hi;
+    uint32_t rpt, n_tiles;
+};
+
+Geometry make_geometry(const void *d_text, size_t n) {
+    Geometry g;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_text);
+    g.base = reinterpret_cast<const uint8_t *>(a & ~static_cast<uintptr_t>(15));
+    g.lo = a & 15;
+    g.hi = g.lo + n;
+    // Aim for >= 8192 tiles (32 per CU) before growing the tile towards 64 KiB.
+    uint32_t rpt = 1;
+    while (rpt < et::MAX_ROUNDS_PER_TILE && g.hi / (static_cast<uint64_t>(rpt) * et::ROUND_BYTES) > 8192) rpt <<= 1;
+    g.rpt = rpt;
+    const uint64_t tile_bytes = static_cast<uint64_t>(rpt) * et::ROUND_BYTES;
+    g.n_tiles = static_cast<uint32_t>((g.hi + tile_bytes - 1) / tile_bytes);
+    return g;
+}
+
+int ensure_encode_ws(et_ctx *ctx, uint32_t n_tiles) {
+    ET_TRY(ensure(ctx, ctx->tile_hist, static_cast<size_t>(n_tiles) * 256 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->block_hist, static_cast<size_t>(et::MAX_GRID) * 256 * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->hist, 256 * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->tile_bits, (static_cast<size_t>(n_tiles) + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->tile_off, (static_cast<size_t>(n_tiles) + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->enc_table, 256 * 2 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->len_table, 256 * sizeof(uint32_t)));
+    return ET_OK;
+}
+
+void record(et_ctx *ctx, int i) {
+    if (ctx->timing) (void)hipEventRecord(ctx->ev[i], ctx->stream);
+}
+
+float elapsed(et_ctx *ctx, int a, int b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) ms = 0.f;
+    return ms;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) {
+    ET_TRY(ensure_encode_ws(ctx, g.n_tiles));
+    et::launch_hist(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<uint32_t *>(ctx->tile_hist.p),
+                    static_cast<unsigned long long *>(ctx->block_hist.p), static_cast<unsigned long long *>(ctx->hist.p));
+    ET_HIP(hipGetLastError());
+    ctx->hist_text = d_text;
+    ctx->hist_n = n;
+    ctx->hist_rpt = g.rpt;
+    ctx->hist_tiles = g.n_tiles;
+    ctx->hist_on_host = false;
+    return ET_OK;
+}
+
+// Upload the code table and run K2 + K4 for the text whose tile histograms are in ctx.
+int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *out32, uint64_t base_bit,
+             const uint8_t *header, size_t header_len, int ev_scan, int ev_body) {
+    const bool long_codes = cb->max_length > 32;
+    record(ctx, 4);
+    for (int s = 0; s < 256; ++s) {
+        const uint32_t len = cb->length[s];
+        uint32_t code = cb->data[s];
+        if (!long_codes) code = len ? (len == 32 ? code : (code & ((1u << len) - 1u)) << (32 - len)) : 0u;  // left-aligned
+        ctx->h_enc[2 * s] = code;
+        ctx->h_enc[2 * s + 1] = len;
+        ctx->h_len[s] = len;
+    }
+    ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ET_HIP(hipMemcpyAsync(ctx->len_table.p, ctx->h_len, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    et::launch_tile_scan(ctx->stream, static_cast<const uint32_t *>(ctx->tile_hist.p), g.n_tiles,
+                         static_cast<const uint32_t *>(ctx->len_table.p), static_cast<unsigned long long *>(ctx->tile_bits.p), base_bit,
+                         static_cast<unsigned long long *>(ctx->tile_off.p), out32);
+    ET_HIP(hipGetLastError());
+    if (header_len) {
+        // After the scan (which zeroes the word holding the header/body seam), before K4.
+        const size_t padded = (header_len + 3) & ~static_cast<size_t>(3);
+        ET_HIP(hipMemcpyAsync(out32, header, padded, hipMemcpyHostToDevice, ctx->stream));
+    }
+    record(ctx, ev_scan);
+    et::launch_encode(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<const unsigned long long *>(ctx->tile_off.p),
+                      static_cast<const uint2 *>(ctx->enc_table.p), cb->max_length, out32);
+    ET_HIP(hipGetLastError());
+    record(ctx, ev_body);
+    return ET_OK;
+}
+
+int fetch_histogram(et_ctx *ctx) {
+    if (ctx->hist_on_host) return ET_OK;
+    ET_HIP(hipMemcpyAsync(ctx->h_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->hist_on_host = true;
+    return ET_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+extern "C" const char *et_version(void) { return "entreepy-hip 0.1.0 (gfx950; .et format 0x01, reference v1.1.0)"; }
+
+extern "C" const char *et_strerror(int status) {
+    switch (status) {
+        case ET_OK: return "ok";
+        case ET_ERR_EMPTY: return "empty input (error.QueueEmpty)";
+        case ET_ERR_NOMEM: return "out of memory";
+        case ET_ERR_CAP: return "output buffer too small";
+        case ET_ERR_FORMAT: return "malformed .et stream";
+        case ET_ERR_HIP: return "HIP runtime error";
+        case ET_ERR_ARG: return "invalid argument";
+        case ET_ERR_UNSUPPORTED: return "unsupported stream (code length > 32)";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char *et_last_error(const et_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" size_t et_encode_bound(size_t n) { return (n + 7200 + 15) & ~static_cast<size_t>(15); }
+
+extern "C" int et_ctx_create(int device, et_ctx **out) {
+    if (!out) return ET_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return ET_ERR_HIP;
+    et_ctx *ctx = new (std::nothrow) et_ctx();
+    if (!ctx) return ET_ERR_NOMEM;
+    ctx->device = device;
+    DeviceGuard guard(device);
+    bool ok = guard.ok;
+    ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+    ctx->stream = ctx->own_stream;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hist), 256 * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_len), 256 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), sizeof(uint16_t) << et::DEC_LUT_BITS_MAX) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_long), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 4 * sizeof(uint64_t)) == hipSuccess;
+    for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) {
+        et_ctx_destroy(ctx);
+        return ET_ERR_HIP;
+    }
+    *out = ctx;
+    return ET_OK;
+}
+
+extern "C" void et_ctx_destroy(et_ctx *ctx) {
+    if (!ctx) return;
+    DeviceGuard guard(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->len_table,
+                      &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->longc, &ctx->flag,
+                      &ctx->io_in, &ctx->io_out};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_len, ctx->h_header, ctx->h_lut, ctx->h_long, ctx->h_scalar};
+    for (void *p : pinned)
+        if (p) (void)hipHostFree(p);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int et_ctx_set_stream(et_ctx *ctx, void *hip_stream) {
+    if (!ctx) return ET_ERR_ARG;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return ET_OK;
+}
+
+extern "C" int et_ctx_enable_timing(et_ctx *ctx, int on) {
+    if (!ctx) return ET_ERR_ARG;
+    ctx->timing = on != 0;
+    return ET_OK;
+}
+
+extern "C" int et_last_timings(const et_ctx *ctx, et_timings *out) {
+    if (!ctx || !out) return ET_ERR_ARG;
+    *out = ctx->tm;
+    return ET_OK;
+}
+
+extern "C" int et_last_codebook(const et_ctx *ctx, et_codebook *out) {
+    if (!ctx || !out) return ET_ERR_ARG;
+    if (!ctx->have_cb) return ET_ERR_ARG;
+    *out = ctx->last_cb;
+    return ET_OK;
+}
+
+extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
+    if (!ctx) return ET_ERR_ARG;
+    DeviceGuard guard(ctx->device);
+    const Geometry g = make_geometry(reinterpret_cast<const void *>(static_cast<uintptr_t>(15)), max_text_bytes);
+    ET_TRY(ensure_encode_ws(ctx, g.n_tiles + 1));
+    // decode: the body is at most ~max_text_bytes (+ header) bytes
+    const uint64_t n_subs = (static_cast<uint64_t>(max_text_bytes) + 8192) * 8 / et::SUB_BITS + 2;
+    const uint64_t n_blocks = n_subs / et::BLOCK + 2;
+    ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_exit, n_blocks * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_count, n_blocks * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_off, (n_blocks + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint16_t) << et::DEC_LUT_BITS_MAX));
+    ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->flag, 64));
+    return ET_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// encode
+// ---------------------------------------------------------------------------------
+extern "C" int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, void *d_hist) {
+    if (!ctx || !d_hist || (n && !d_text)) return ET_ERR_ARG;
+    DeviceGuard guard(ctx->device);
+    if (n == 0) {
+        ET_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), ctx->stream));
+        ctx->hist_text = nullptr;
+        return ET_OK;
+    }
+    const Geometry g = make_geometry(d_text, n);
+    ET_TRY(run_histogram(ctx, d_text, n, g));
+    ET_HIP(hipMemcpyAsync(d_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return ET_OK;
+}
+
+extern "C" int et_encode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n, void *d_out, size_t cap_bytes,
+                                     uint64_t start_bit, uint64_t *end_bit) {
+    if (!ctx || !cb || !d_out || !end_bit || (n && !d_text)) return ET_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_out) & 3) return fail(ctx, ET_ERR_ARG, "d_out must be 4-byte aligned");
+    if (n == 0) {
+        *end_bit = start_bit;
+        return ET_OK;
+    }
+    if (ctx->hist_text != d_text || ctx->hist_n != n)
+        return fail(ctx, ET_ERR_ARG, "et_encode_body_device needs et_histogram_device on the same (d_text, n) first");
+    DeviceGuard guard(ctx->device);
+    ET_TRY(fetch_histogram(ctx));
+    ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned code-table staging may still feed an earlier call
+    uint64_t bits = 0;
+    et_codebook_bits(cb, ctx->h_hist, &bits);
+    const uint64_t end = start_bit + bits;
+    if (((end + 31) / 32) * 4 > cap_bytes) return fail(ctx, ET_ERR_CAP, "body does not fit d_out");
+    Geometry g = make_geometry(d_text, n);
+    g.rpt = ctx->hist_rpt;
+    g.n_tiles = ctx->hist_tiles;
+    ET_TRY(run_body(ctx, cb, g, static_cast<uint32_t *>(d_out), start_bit, nullptr, 0, 2, 3));
+    *end_bit = end;
+    return ET_OK;
+}
+
+extern "C" int et_encode_device(et_ctx *ctx, const void *d_text, size_t n, void *d_out, size_t cap, size_t *out_len) {
+    if (!ctx || !d_out || !out_len || (n && !d_text)) return ET_ERR_ARG;
+    if (n == 0) return fail(ctx, ET_ERR_EMPTY, "empty input");
+    if (reinterpret_cast<uintptr_t>(d_out) & 15) return fail(ctx, ET_ERR_ARG, "d_out must be 16-byte aligned");
+    if (cap < et_encode_bound(n)) return fail(ctx, ET_ERR_CAP, "cap < et_encode_bound(n)");
+    DeviceGuard guard(ctx->device);
+    const Geometry g = make_geometry(d_text, n);
+    record(ctx, 0);
+    ET_TRY(run_histogram(ctx, d_text, n, g));
+    record(ctx, 1);
+    ET_TRY(fetch_histogram(ctx));
+    const double t1 = now_ms();
+
+    et_codebook cb;
+    int rc = et_build_codebook(ctx->h_hist, &cb);
+    if (rc != ET_OK) return fail(ctx, rc, "et_build_codebook");
+    ctx->last_cb = cb;
+    ctx->have_cb = true;
+    size_t header_len = 0;
+    std::memset(ctx->h_header, 0, HEADER_STAGE);
+    rc = et_write_header(&cb, n, ctx->h_header, HEADER_STAGE - 4, &header_len);
+    if (rc != ET_OK) return fail(ctx, rc, "et_write_header");
+    uint64_t bits = 0;
+    et_codebook_bits(&cb, ctx->h_hist, &bits);
+    const double t2 = now_ms();
+
+    if (bits == 0) {
+        // Single distinct symbol: the whole file is the 9-byte header (encode.zig:137-138, :270-275).
+        const size_t padded = (header_len + 3) & ~static_cast<size_t>(3);
+        ET_HIP(hipMemcpyAsync(d_out, ctx->h_header, padded, hipMemcpyHostToDevice, ctx->stream));
+        record(ctx, 2);
+        record(ctx, 3);
+    } else {
+        ET_TRY(run_body(ctx, &cb, g, static_cast<uint32_t *>(d_out), static_cast<uint64_t>(header_len) * 8, ctx->h_header, header_len, 2, 3));
+    }
+    *out_len = header_len + static_cast<size_t>((bits + 7) / 8);  // encode.zig:318,336
+    if (ctx->timing) {
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->tm = et_timings{};
+        ctx->tm.hist_ms = elapsed(ctx, 0, 1);
+        ctx->tm.host_ms = static_cast<float>(t2 - t1);
+        ctx->tm.scan_ms = bits ? elapsed(ctx, 4, 2) : 0.f;
+        ctx->tm.body_ms = elapsed(ctx, 2, 3);
+        ctx->tm.total_ms = elapsed(ctx, 0, 3);
+    }
+    return ET_OK;
+}
+
+extern "C" int et_encode(et_ctx *ctx, const uint8_t *text, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!ctx || !out || !out_len || (n && !text)) return ET_ERR_ARG;
+    if (n == 0) return fail(ctx, ET_ERR_EMPTY, "empty input");
+    DeviceGuard guard(ctx->device);
+    const size_t bound = et_encode_bound(n);
+    ET_TRY(ensure(ctx, ctx->io_in, n + 16));
+    ET_TRY(ensure(ctx, ctx->io_out, bound + 16));
+    ET_HIP(hipMemcpyAsync(ctx->io_in.p, text, n, hipMemcpyHostToDevice, ctx->stream));
+    size_t len = 0;
+    ET_TRY(et_encode_device(ctx, ctx->io_in.p, n, ctx->io_out.p, bound, &len));
+    if (len > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
+    ET_HIP(hipMemcpyAsync(out, ctx->io_out.p, len, hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = len;
+    return ET_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------
+namespace {
+
+// First-level table indexed by the next lut_bits bits; codes longer than that go to
+// a short list searched linearly (they are the rare symbols by construction).
+void build_decode_tables(const et_codebook *cb, uint16_t *lut, uint32_t *longc, uint32_t *lut_bits, uint32_t *n_long) {
+    const uint32_t k = cb->max_length < et::DEC_LUT_BITS_MAX ? (cb->max_length ? cb->max_length : 1) : et::DEC_LUT_BITS_MAX;
+    std::memset(lut, 0, sizeof(uint16_t) << k);
+    uint32_t nl = 0;
+    for (int s = 0; s < 256; ++s) {
+        const uint32_t len = cb->length[s];
+        if (!len) continue;
+        const uint32_t code = cb->data[s];
+        const uint32_t meta = (len << 8) | static_cast<uint32_t>(s);
+        if (len <= k) {
+            const uint32_t first = code << (k - len), span = 1u << (k - len);
+            for (uint32_t i = 0; i < span; ++i) lut[first + i] = static_cast<uint16_t>(meta);
+        } else {
+            longc[2 * nl] = code << (32 - len);
+            longc[2 * nl + 1] = meta;
+            ++nl;
+        }
+    }
+    *lut_bits = k;
+    *n_long = nl;
+}
+
+}  // namespace
+
+extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body, size_t body_bytes, uint32_t start_bit,
+                                     uint64_t n_symbols, void *d_out, size_t cap, size_t *out_len) {
+    if (!ctx || !cb || !out_len) return ET_ERR_ARG;
+    *out_len = 0;
+    if (cb->max_length > 32) return fail(ctx, ET_ERR_UNSUPPORTED, "code length > 32");
+    if (start_bit >= 8) return fail(ctx, ET_ERR_ARG, "start_bit must be < 8");
+    if (n_symbols == 0 || body_bytes == 0 || cb->n_coded == 0 || static_cast<uint64_t>(body_bytes) * 8 <= start_bit) return ET_OK;
+    if (!d_body || !d_out) return ET_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_out) & 15) return fail(ctx, ET_ERR_ARG, "d_out must be 16-byte aligned");
+    DeviceGuard guard(ctx->device);
+
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_body);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(a & ~static_cast<uintptr_t>(3));
+    const uint32_t first_bit = static_cast<uint32_t>(a & 3) * 8 + start_bit;
+    const uint64_t n_bytes = (a & 3) + body_bytes;  // stream bytes measured from the aligned base
+    const uint64_t n_subs = (n_bytes * 8 + et::SUB_BITS - 1) / et::SUB_BITS;
+    const uint64_t n_blocks64 = (n_subs + et::BLOCK - 1) / et::BLOCK;
+    if (n_blocks64 > 0x7fffffffull) return fail(ctx, ET_ERR_ARG, "body too large");
+    const uint32_t n_blocks = static_cast<uint32_t>(n_blocks64);
+
+    ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint16_t) << et::DEC_LUT_BITS_MAX));
+    ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->flag, 64));
+
+    const double t0 = now_ms();
+    ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
+    uint32_t lut_bits = 0, n_long = 0;
+    build_decode_tables(cb, ctx->h_lut, ctx->h_long, &lut_bits, &n_long);
+    const double t1 = now_ms();
+    record(ctx, 0);
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, sizeof(uint16_t) << lut_bits, hipMemcpyHostToDevice, ctx->stream));
+    if (n_long) ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, n_long * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+
+    const uint16_t *lut = static_cast<const uint16_t *>(ctx->lut.p);
+    const uint32_t *longc = static_cast<const uint32_t *>(ctx->longc.p);
+    uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
+    uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
+    uint32_t *blk_count = static_cast<uint32_t *>(ctx->blk_count.p);
+    uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
+    unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
+
+    // D1: sweep 0 guesses, later sweeps repair; stop after a sweep that changed nothing.
+    uint32_t iters = 0;
+    et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, lut, longc, lut_bits, n_long, 0, sub_state, blk_exit, blk_count, flag);
+    ET_HIP(hipGetLastError());
+    ++iters;
+    for (;;) {
+        ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, lut, longc, lut_bits, n_long, iters, sub_state, blk_exit, blk_count, flag);
+        ET_HIP(hipGetLastError());
+        ++iters;
+        ET_HIP(hipMemcpyAsync(ctx->h_scalar, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        if (*reinterpret_cast<const uint32_t *>(ctx->h_scalar) == 0) break;
+        if (iters > n_blocks + 2) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
+    }
+    record(ctx, 1);
+
+    // D2
+    et::launch_dec_scan(ctx->stream, blk_count, n_blocks, blk_off);
+    ET_HIP(hipGetLastError());
+    ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    record(ctx, 2);
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t decodable = ctx->h_scalar[1];
+    const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
+    if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
+
+    // D3
+    if (n_out) {
+        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, lut, longc, lut_bits, n_long, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out));
+        ET_HIP(hipGetLastError());
+    }
+    record(ctx, 3);
+    *out_len = static_cast<size_t>(n_out);
+    if (ctx->timing) {
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->tm = et_timings{};
+        ctx->tm.host_ms = static_cast<float>(t1 - t0);
+        ctx->tm.sync_ms = elapsed(ctx, 0, 1);
+        ctx->tm.scan_ms = elapsed(ctx, 1, 2);
+        ctx->tm.body_ms = elapsed(ctx, 2, 3);
+        ctx->tm.total_ms = elapsed(ctx, 0, 3);
+        ctx->tm.sync_iters = iters;
+    }
+    return ET_OK;
+}
+
+extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t len, void *d_out, size_t cap, size_t *out_len) {
+    if (!ctx || !d_compressed || !out_len) return ET_ERR_ARG;
+    *out_len = 0;
+    if (len < 5) return fail(ctx, ET_ERR_FORMAT, "stream shorter than its header");
+    DeviceGuard guard(ctx->device);
+    // The header and dictionary (<= 4627 bytes after the 4 stripped ones) are parsed on the host.
+    const size_t head = len < HEADER_STAGE ? len : HEADER_STAGE;
+    std::vector<uint8_t> hdr(head);
+    ET_HIP(hipMemcpyAsync(hdr.data(), d_compressed, head, hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    et_codebook cb;
+    uint64_t n_symbols = 0;
+    size_t body_offset = 0;
+    // Parsing only needs the dictionary; give the parser the true length when the
+    // stream is short so that truncation is detected, else the staged prefix.
+    int rc = et_parse_header(hdr.data(), head, &cb, &n_symbols, &body_offset);
+    if (rc != ET_OK) return fail(ctx, rc, "et_parse_header");
+    if (body_offset > len) return fail(ctx, ET_ERR_FORMAT, "dictionary runs past the end of the stream");
+    return et_decode_body_device(ctx, &cb, static_cast<const uint8_t *>(d_compressed) + body_offset, len - body_offset, 0, n_symbols, d_out, cap, out_len);
+}
+
+extern "C" int et_decode(et_ctx *ctx, const uint8_t *compressed, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!ctx || !compressed || !out_len) return ET_ERR_ARG;
+    *out_len = 0;
+    if (len < 5) return fail(ctx, ET_ERR_FORMAT, "stream shorter than its header");
+    DeviceGuard guard(ctx->device);
+    size_t n_symbols = 0;
+    et_decoded_size(compressed, len, &n_symbols);
+    ET_TRY(ensure(ctx, ctx->io_in, len + 16));
+    ET_TRY(ensure(ctx, ctx->io_out, n_symbols + 64));
+    ET_HIP(hipMemcpyAsync(ctx->io_in.p, compressed, len, hipMemcpyHostToDevice, ctx->stream));
+    size_t n_out = 0;
+    ET_TRY(et_decode_device(ctx, ctx->io_in.p, len, ctx->io_out.p, n_symbols + 64, &n_out));
+    if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
+    if (n_out) {
+        if (!out) return ET_ERR_ARG;
+        ET_HIP(hipMemcpyAsync(out, ctx->io_out.p, n_out, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = n_out;
+    return ET_OK;
+}

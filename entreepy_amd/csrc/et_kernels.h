@@ -1,0 +1,35 @@
+// et_kernels.h -- geometry constants and launch wrappers of et_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace et {
+
+constexpr int BLOCK = 256;                    // threads per workgroup: 4 wavefronts of 64
+constexpr uint32_t ROUND_BYTES = BLOCK * 16;  // one 16-byte load per lane
+constexpr uint32_t MAX_ROUNDS_PER_TILE = 16;  // tile <= 64 KiB (u32 tile counters, u32 bit cursors)
+constexpr int HIST_REP = 4;                   // lane-interleaved counter replicas per wavefront
+constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-stride beyond
+
+constexpr uint32_t SUB_BITS = 256;                             // decode: bits per lane subsequence
+constexpr uint32_t DEC_BLOCK_WORDS = BLOCK * SUB_BITS / 32;    // 8 KiB of bitstream per workgroup
+constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: 4096 x u16 in LDS
+constexpr uint32_t DEC_STAGE_BYTES = 16384;                    // LDS staging of decoded symbols
+
+void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
+                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist);
+uint32_t hist_rows(uint32_t n_tiles);
+void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
+                      unsigned long long *tile_bits, unsigned long long base_bit, unsigned long long *tile_off, uint32_t *out32);
+void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
+                   const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32);
+void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
+                     const uint16_t *lut, const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, uint32_t iter,
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed);
+void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *blk_off);
+void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const uint16_t *lut,
+                      const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, const uint32_t *sub_state,
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out);
+
+}  // namespace et

@@ -1,0 +1,699 @@
+// et_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the entreepy
+// Huffman path.  Pure integer/bit work: no MFMA; the bounds are HBM bandwidth, the
+// LDS pipe (atomics + table reads) and VALU issue.
+//
+//   encode.zig:43-47   -> k_hist_tiles (+ k_hist_reduce)          "K1"
+//   encode.zig:308-313 -> k_tile_bits, k_tile_scan                "K2" (the serial
+//                         bits_written counter turned into a scan over tiles)
+//   encode.zig:303-315 -> k_encode_tiles / k_encode_tiles_long    "K4"
+//   decode.zig:143-203 -> k_dec_sync, k_dec_scan, k_dec_write     "D1..D3"
+//
+// Geometry shared by every kernel: workgroups of 256 threads (4 wavefronts of 64).
+// Encode side: a "round" is 4 KiB of input, one 16-byte load per lane, fully
+// coalesced; a "tile" is 1..16 consecutive rounds and is the unit for which K1
+// leaves a 256-bin histogram and K4 gets a start bit offset.
+#include "et_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace et {
+
+// --------------------------------------------------------------------------------
+// wavefront / workgroup scans (DPP, no LDS traffic inside a wavefront)
+// --------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
+    return x + static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false));
+}
+
+// Inclusive prefix sum over the 64 lanes of a wavefront.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+    x = dpp_add<0x111, 0xf>(x);  // row_shr:1
+    x = dpp_add<0x112, 0xf>(x);  // row_shr:2
+    x = dpp_add<0x114, 0xf>(x);  // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);  // row_shr:8  -> each row of 16 scanned
+    x = dpp_add<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// Exclusive prefix sum over the 256 threads of a workgroup; *total = sum of all.
+// `scratch` is 4 LDS words.  Contains ONE barrier; the caller must separate two
+// calls that reuse `scratch` by another barrier.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *scratch, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(x);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    const uint32_t w0 = scratch[0], w1 = scratch[1], w2 = scratch[2], w3 = scratch[3];
+    uint32_t before = 0;
+    if (wave > 0) before += w0;
+    if (wave > 1) before += w1;
+    if (wave > 2) before += w2;
+    *total = w0 + w1 + w2 + w3;
+    return before + inc - x;
+}
+
+// --------------------------------------------------------------------------------
+// input addressing
+// --------------------------------------------------------------------------------
+// The text is addressed relative to a 16-byte aligned base: the stream occupies
+// bytes [lo, hi) of it (lo < 16).  A lane's 16-byte chunk is loaded with one
+// dwordx4 when it lies fully inside [lo, hi); the (at most two) partial chunks of a
+// stream are assembled from guarded byte loads so nothing outside it is touched.
+struct Chunk {
+    uint32_t w[4];
+    uint32_t valid;  // bit k set <=> byte k belongs to the stream
+};
+
+__device__ __forceinline__ Chunk load_chunk(const uint8_t *__restrict__ base, uint64_t off, uint64_t lo, uint64_t hi) {
+    Chunk c;
+    if (off >= lo && off + 16 <= hi) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + off);
+        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+        c.valid = 0xffffu;
+    } else {
+        c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+        c.valid = 0;
+        if (off < hi && off + 16 > lo) {
+            for (int k = 0; k < 16; ++k) {
+                const uint64_t p = off + k;
+                if (p >= lo && p < hi) {
+                    c.w[k >> 2] |= static_cast<uint32_t>(base[p]) << (8 * (k & 3));
+                    c.valid |= 1u << k;
+                }
+            }
+        }
+    }
+    return c;
+}
+
+// --------------------------------------------------------------------------------
+// K1: byte histogram with per-wavefront LDS privatisation
+// --------------------------------------------------------------------------------
+// LDS layout [wave][bin][HIST_REP] u32: every wavefront owns a private set of
+// counters, and inside it HIST_REP lane-interleaved replicas (replica = lane &
+// (HIST_REP-1)) split the same-address ds_add serialisation that skewed text causes.
+// Bank of a counter = (bin * HIST_REP + rep) mod 32, so the 32 lanes of a half-wave
+// spread over all banks.  Counters are u32 (a tile is at most 64 KiB); tile totals
+// go out as u32, workgroup totals as u64.
+__global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
+                                                      uint32_t rounds_per_tile, uint32_t n_tiles,
+                                                      uint32_t *__restrict__ tile_hist,
+                                                      unsigned long long *__restrict__ block_hist) {
+    __shared__ __attribute__((aligned(16))) uint32_t sh[4 * 256 * HIST_REP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * 256 * HIST_REP; i += BLOCK) sh[i] = 0;
+    __syncthreads();
+
+    uint32_t *mine = sh + wave * 256 * HIST_REP + (lane & (HIST_REP - 1));
+    unsigned long long acc = 0;  // thread `tid` owns bin `tid` of the workgroup total
+    const uint64_t tile_bytes = static_cast<uint64_t>(rounds_per_tile) * ROUND_BYTES;
+
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(tid) * 16;
+        Chunk cur = load_chunk(base, t0, lo, hi);
+        for (uint32_t r = 0; r < rounds_per_tile; ++r) {
+            Chunk nxt;
+            nxt.valid = 0;
+            if (r + 1 < rounds_per_tile) nxt = load_chunk(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi);
+            if (cur.valid == 0xffffu) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t sym = (cur.w[d] >> (8 * b)) & 0xffu;
+                        atomicAdd(mine + sym * HIST_REP, 1u);  // ds_add_u32, no return
+                    }
+                }
+            } else if (cur.valid) {
+                for (int k = 0; k < 16; ++k)
+                    if (cur.valid & (1u << k)) atomicAdd(mine + ((cur.w[k >> 2] >> (8 * (k & 3))) & 0xffu) * HIST_REP, 1u);
+            }
+            cur = nxt;
+        }
+        __syncthreads();
+        // Tile flush: thread = bin; sum the 4 wavefront copies x HIST_REP replicas.
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t *p = sh + (w * 256 + tid) * HIST_REP;
+#pragma unroll
+            for (int r = 0; r < HIST_REP; ++r) {
+                total += p[r];
+                p[r] = 0;
+            }
+        }
+        tile_hist[static_cast<uint64_t>(t) * 256 + tid] = total;
+        acc += total;
+        __syncthreads();
+    }
+    block_hist[static_cast<uint64_t>(blockIdx.x) * 256 + tid] = acc;
+}
+
+// Column sums of block_hist[n_rows][256] into hist[256] (zeroed beforehand).
+__global__ __launch_bounds__(BLOCK) void k_hist_reduce(const unsigned long long *__restrict__ block_hist, uint32_t n_rows,
+                                                       unsigned long long *__restrict__ hist) {
+    unsigned long long s = 0;
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) s += block_hist[static_cast<uint64_t>(r) * 256 + threadIdx.x];
+    if (s) atomicAdd(hist + threadIdx.x, s);
+}
+
+// --------------------------------------------------------------------------------
+// K2: tile bit totals and their exclusive scan
+// --------------------------------------------------------------------------------
+// One wavefront per tile: lane l holds the code lengths of bins 4l..4l+3 and reads
+// the tile's counts for them with one 16-byte load.
+__global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict__ tile_hist, uint32_t n_tiles,
+                                                     const uint32_t *__restrict__ lengths,
+                                                     unsigned long long *__restrict__ tile_bits) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const uint4 len4 = reinterpret_cast<const uint4 *>(lengths)[lane];
+    for (uint32_t t = wave_global; t < n_tiles; t += n_waves) {
+        const uint4 c = reinterpret_cast<const uint4 *>(tile_hist + static_cast<uint64_t>(t) * 256)[lane];
+        unsigned long long s = static_cast<unsigned long long>(c.x) * len4.x + static_cast<unsigned long long>(c.y) * len4.y +
+                               static_cast<unsigned long long>(c.z) * len4.z + static_cast<unsigned long long>(c.w) * len4.w;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) tile_bits[t] = s;
+    }
+}
+
+// Single-workgroup exclusive scan: tile_off[t] = base_bit + sum(tile_bits[0..t)),
+// tile_off[n_tiles] = end bit.  Also zeroes every 32-bit output word that holds a
+// tile boundary: those are the only words two workgroups of K4 may share, and K4
+// merges into them with atomicOr.
+__global__ __launch_bounds__(1024) void k_tile_scan(const unsigned long long *__restrict__ tile_bits, uint32_t n_tiles,
+                                                    unsigned long long base_bit, unsigned long long *__restrict__ tile_off,
+                                                    uint32_t *__restrict__ out32) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = base_bit;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_tiles; c0 += 1024) {
+        const uint32_t t = c0 + tid;
+        const unsigned long long x = (t < n_tiles) ? tile_bits[t] : 0ull;
+        const unsigned long long inc = wave_inclusive_scan64(x);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const unsigned long long excl = before + inc - x;
+        if (t < n_tiles) {
+            tile_off[t] = excl;
+            out32[excl >> 5] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        tile_off[n_tiles] = carry_s;
+        out32[carry_s >> 5] = 0;
+    }
+}
+
+// --------------------------------------------------------------------------------
+// K4: variable-length code scatter
+// --------------------------------------------------------------------------------
+// Per round every lane looks its 16 symbols up in an LDS copy of the code table
+// ({left-aligned code, length}), the workgroup scans the per-lane bit totals, and
+// each lane then ORs its bits into an LDS ring of 32-bit big-endian words
+// (ds_or_b32).  Completed words leave the ring as coalesced dword stores; the word a
+// tile shares with its neighbour is merged with a global atomicOr.
+struct RingFlush {
+    uint32_t *ring;
+    uint32_t *out32;             // global word 0 of this tile
+    bool first_word_shared;      // tile does not start on a word boundary
+};
+
+template <uint32_t RING_WORDS>
+__device__ __forceinline__ void flush_words(const RingFlush &f, uint32_t from, uint32_t to) {
+    for (uint32_t i = from + threadIdx.x; i < to; i += BLOCK) {
+        const uint32_t slot = i & (RING_WORDS - 1);
+        const uint32_t v = __builtin_bswap32(f.ring[slot]);
+        f.ring[slot] = 0;
+        if (i == 0 && f.first_word_shared) atomicOr(f.out32, v);
+        else f.out32[i] = v;
+    }
+}
+
+template <uint32_t RING_WORDS>
+__global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
+                                                        uint32_t rounds_per_tile, uint32_t n_tiles,
+                                                        const unsigned long long *__restrict__ tile_off,
+                                                        const uint2 *__restrict__ enc_table, uint32_t *__restrict__ out32) {
+    __shared__ __attribute__((aligned(16))) uint32_t ring[RING_WORDS];
+    __shared__ __attribute__((aligned(16))) uint2 tab[256];
+    __shared__ uint32_t scratch[2][4];
+    const int tid = threadIdx.x;
+    tab[tid] = enc_table[tid];
+    for (uint32_t i = tid; i < RING_WORDS; i += BLOCK) ring[i] = 0;
+    __syncthreads();
+
+    const uint64_t tile_bytes = static_cast<uint64_t>(rounds_per_tile) * ROUND_BYTES;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const unsigned long long bit0 = tile_off[t];
+        RingFlush f;
+        f.ring = ring;
+        f.out32 = out32 + (bit0 >> 5);
+        f.first_word_shared = (bit0 & 31) != 0;
+        uint32_t run = static_cast<uint32_t>(bit0 & 31);  // bit cursor relative to the tile's first word
+        uint32_t flushed = 0;                             // ring words already stored
+        const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(tid) * 16;
+
+        Chunk cur = load_chunk(base, t0, lo, hi);
+        for (uint32_t r = 0; r < rounds_per_tile; ++r) {
+            Chunk nxt;
+            nxt.valid = 0;
+            nxt.w[0] = nxt.w[1] = nxt.w[2] = nxt.w[3] = 0;
+            if (r + 1 < rounds_per_tile) nxt = load_chunk(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi);
+
+            uint32_t code[16], len[16];
+            uint32_t tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint2 e = tab[(cur.w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+                const bool ok = (cur.valid >> k) & 1u;
+                code[k] = ok ? e.x : 0u;
+                len[k] = ok ? e.y : 0u;
+                tot += len[k];
+            }
+            uint32_t round_total;
+            const uint32_t excl = block_exclusive_scan(tot, scratch[r & 1], &round_total);
+
+            uint32_t pos = run + excl;
+            uint32_t w = pos >> 5, fill = pos & 31;
+            unsigned long long acc = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc |= static_cast<unsigned long long>(code[k]) << (32 - fill);
+                fill += len[k];
+                if (fill >= 32) {
+                    atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
+                    acc <<= 32;
+                    fill -= 32;
+                    ++w;
+                }
+            }
+            if (fill) atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
+            run += round_total;
+            __syncthreads();
+            flush_words<RING_WORDS>(f, flushed, run >> 5);
+            flushed = run >> 5;
+            cur = nxt;
+        }
+        // The open word at the tile's end is shared with the next tile (or is the
+        // stream's zero-padded last word).
+        if ((run & 31) && tid == 0) {
+            const uint32_t slot = flushed & (RING_WORDS - 1);
+            atomicOr(f.out32 + flushed, __builtin_bswap32(ring[slot]));
+            ring[slot] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// Same job for code tables with a length above 32 bits.  The reference emits bit
+// (data >> ((j-1) & 31)) & 1 for j = len..1 (encode.zig:311), i.e. the low
+// ((len-1)&31)+1 bits of data followed by whole copies of data: a code is a sequence
+// of pieces of at most 32 bits.  One symbol per lane per step; enc_table holds
+// {data, len}.  Rare path (needs a Fibonacci-like histogram), kept simple.
+__global__ __launch_bounds__(BLOCK) void k_encode_tiles_long(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
+                                                             uint32_t rounds_per_tile, uint32_t n_tiles,
+                                                             const unsigned long long *__restrict__ tile_off,
+                                                             const uint2 *__restrict__ enc_table, uint32_t *__restrict__ out32) {
+    constexpr uint32_t RING_WORDS = 4096;  // one step emits at most 256 * 255 bits = 2040 words
+    __shared__ uint32_t ring[RING_WORDS];
+    __shared__ uint2 tab[256];
+    __shared__ uint32_t scratch[2][4];
+    const int tid = threadIdx.x;
+    tab[tid] = enc_table[tid];
+    for (uint32_t i = tid; i < RING_WORDS; i += BLOCK) ring[i] = 0;
+    __syncthreads();
+
+    const uint64_t tile_bytes = static_cast<uint64_t>(rounds_per_tile) * ROUND_BYTES;
+    const uint32_t steps = rounds_per_tile * (ROUND_BYTES / BLOCK);
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const unsigned long long bit0 = tile_off[t];
+        RingFlush f;
+        f.ring = ring;
+        f.out32 = out32 + (bit0 >> 5);
+        f.first_word_shared = (bit0 & 31) != 0;
+        uint32_t run = static_cast<uint32_t>(bit0 & 31), flushed = 0;
+        for (uint32_t s = 0; s < steps; ++s) {
+            const uint64_t p = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(s) * BLOCK + tid;
+            uint32_t data = 0, len = 0;
+            if (p >= lo && p < hi) {
+                const uint2 e = tab[base[p]];
+                data = e.x;
+                len = e.y;
+            }
+            uint32_t step_total;
+            const uint32_t excl = block_exclusive_scan(len, scratch[s & 1], &step_total);
+            uint32_t pos = run + excl;
+            uint32_t remaining = len;
+            while (remaining) {
+                const uint32_t piece = ((remaining - 1) & 31u) + 1;  // bits (remaining-1)&31 .. 0 of data
+                const uint32_t bits = (piece == 32) ? data : (data & ((1u << piece) - 1u));
+                const unsigned long long placed = (static_cast<unsigned long long>(bits) << (32 - piece)) << (32 - (pos & 31));
+                atomicOr(&ring[(pos >> 5) & (RING_WORDS - 1)], static_cast<uint32_t>(placed >> 32));
+                if (static_cast<uint32_t>(placed)) atomicOr(&ring[((pos >> 5) + 1) & (RING_WORDS - 1)], static_cast<uint32_t>(placed));
+                pos += piece;
+                remaining -= piece;
+            }
+            run += step_total;
+            __syncthreads();
+            flush_words<RING_WORDS>(f, flushed, run >> 5);
+            flushed = run >> 5;
+        }
+        if ((run & 31) && tid == 0) {
+            const uint32_t slot = flushed & (RING_WORDS - 1);
+            atomicOr(f.out32 + flushed, __builtin_bswap32(ring[slot]));
+            ring[slot] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------
+// Decode
+// --------------------------------------------------------------------------------
+// The .et body carries no block index, so workgroups cannot know where codewords
+// start.  The bitstream (addressed from a 4-byte aligned base) is cut into
+// subsequences of SUB_BITS bits, one per lane.  State per subsequence, packed in a
+// u32: start (bits past the subsequence's first bit at which its first codeword
+// begins), exit (same for the following subsequence, as implied by `start`) and the
+// number of codewords that begin inside it.  k_dec_sync iterates start[i+1] =
+// exit[i] to a fixed point; Huffman codes self-synchronise, so a wrong guess heals
+// within a few codewords and the fixed point is reached after two or three sweeps.
+// The unique fixed point with start[0] = the true first bit is the true parse.
+struct DecodeTables {
+    const uint16_t *lut;     // [1 << lut_bits]: (len << 8) | sym, len == 0 -> long/invalid
+    const uint32_t *longc;   // [n_long * 2]: {left-aligned code, (len << 8) | sym}
+    uint32_t lut_bits;
+    uint32_t n_long;
+};
+
+__device__ __forceinline__ uint32_t load_be32_guarded(const uint32_t *__restrict__ words, uint64_t idx, uint64_t n_bytes) {
+    // big-endian numeric value of stream bytes [4*idx, 4*idx+4), zero beyond n_bytes
+    const uint64_t b0 = idx * 4;
+    if (b0 + 4 <= n_bytes) return __builtin_bswap32(words[idx]);
+    uint32_t v = 0;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(words);
+    for (int k = 0; k < 4; ++k)
+        if (b0 + k < n_bytes) v |= static_cast<uint32_t>(bytes[b0 + k]) << (24 - 8 * k);
+    return v;
+}
+
+// Stage the workgroup's SUBS_PER_BLOCK subsequences (+2 guard words) into LDS as
+// host-order words whose numeric MSB is the first stream bit.
+__device__ __forceinline__ void stage_block_words(uint32_t *sdata, const uint32_t *__restrict__ words, uint64_t first_word,
+                                                  uint64_t n_bytes) {
+    for (uint32_t i = threadIdx.x; i < DEC_BLOCK_WORDS + 2; i += BLOCK) sdata[i] = load_be32_guarded(words, first_word + i, n_bytes);
+}
+
+__device__ __forceinline__ uint32_t peek32(const uint32_t *sdata, uint32_t rel_bit) {
+    const uint32_t k = rel_bit >> 5, sh = rel_bit & 31;
+    return __funnelshift_l(sdata[k + 1], sdata[k], sh);
+}
+
+// Length and symbol of the codeword at the top of `window`; len == 0 -> no code matches.
+__device__ __forceinline__ uint32_t match_code(const uint16_t *s_lut, const uint32_t *s_long, uint32_t lut_bits, uint32_t n_long,
+                                               uint32_t window) {
+    uint32_t e = s_lut[window >> (32 - lut_bits)];
+    if ((e >> 8) == 0 && n_long) {
+        for (uint32_t i = 0; i < n_long; ++i) {
+            const uint32_t meta = s_long[2 * i + 1], len = meta >> 8;
+            if (((window ^ s_long[2 * i]) >> (32 - len)) == 0) {
+                e = meta;
+                break;
+            }
+        }
+    }
+    return e;
+}
+
+struct SubResult {
+    uint32_t exit_rel;
+    uint32_t count;
+};
+
+// Walk the codewords that begin inside subsequence `sub` of the workgroup's staged
+// data, from `start_rel`.  `limit_rel` = stream end relative to the block's first bit.
+template <bool WRITE>
+__device__ __forceinline__ SubResult walk_subsequence(const uint32_t *sdata, const uint16_t *s_lut, const uint32_t *s_long,
+                                                      uint32_t lut_bits, uint32_t n_long, uint32_t sub, uint32_t start_rel,
+                                                      uint64_t limit_rel, uint8_t *stage, uint32_t stage_pos, uint32_t stage_lo,
+                                                      uint32_t stage_hi) {
+    uint32_t pos = sub * SUB_BITS + start_rel;
+    const uint32_t end = (sub + 1) * SUB_BITS;
+    uint32_t count = 0;
+    while (pos < end) {
+        const uint32_t e = match_code(s_lut, s_long, lut_bits, n_long, peek32(sdata, pos));
+        uint32_t len = e >> 8;
+        const bool valid = len != 0;
+        if (!valid) len = 1;  // not a codeword (only on a wrong guess or a malformed stream): resynchronise bit by bit
+        if (static_cast<uint64_t>(pos) + len > limit_rel) {
+            pos = end;  // ran off the stream: nothing further begins here
+            break;
+        }
+        if (valid) {
+            if (WRITE) {
+                const uint32_t o = stage_pos + count;
+                if (o >= stage_lo && o < stage_hi) stage[o - stage_lo] = static_cast<uint8_t>(e & 0xffu);
+            }
+            ++count;
+        }
+        pos += len;
+    }
+    SubResult r;
+    r.exit_rel = pos - end;
+    r.count = count;
+    return r;
+}
+
+__device__ __forceinline__ void load_decode_tables(const DecodeTables &tb, uint16_t *s_lut, uint32_t *s_long) {
+    const uint32_t n_lut = 1u << tb.lut_bits;
+    for (uint32_t i = threadIdx.x; i < n_lut; i += BLOCK) s_lut[i] = tb.lut[i];
+    for (uint32_t i = threadIdx.x; i < tb.n_long * 2; i += BLOCK) s_long[i] = tb.longc[i];
+}
+
+// D1.  iter == 0: every subsequence guesses that a codeword begins at its first bit
+// (the very first one starts at first_bit, which is exact).  iter > 0: a workgroup
+// whose predecessor's exit still equals the start its lane 0 used returns at once;
+// otherwise it re-runs its local fixed point from the stored state and raises
+// *changed.  blk_exit[b] is read by workgroup b+1 of the SAME launch without
+// ordering: either value is a legal intermediate state, and a launch that ends with
+// *changed == 0 has seen every workgroup consistent with its predecessor.
+__global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit,
+                                                    uint64_t n_subs, DecodeTables tb, uint32_t iter,
+                                                    uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
+                                                    uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed) {
+    __shared__ uint32_t sdata[DEC_BLOCK_WORDS + 2];
+    __shared__ uint16_t s_lut[1 << DEC_LUT_BITS_MAX];
+    __shared__ uint32_t s_long[512];
+    __shared__ uint32_t s_exit[BLOCK];
+    __shared__ uint32_t s_flag;
+    __shared__ uint32_t scratch[4];
+    const int tid = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    const uint64_t sub_g = b * BLOCK + tid;
+    const bool live = sub_g < n_subs;
+
+    uint32_t start, exit_rel = 0, count = 0;
+    bool need;
+    if (iter == 0) {
+        start = (sub_g == 0) ? first_bit : 0u;
+        need = live;
+    } else {
+        const uint32_t st = live ? sub_state[sub_g] : 0u;
+        start = st & 0xffu;
+        exit_rel = (st >> 8) & 0xffu;
+        count = st >> 16;
+        need = false;
+        if (tid == 0) {
+            const uint32_t in = (b == 0) ? first_bit : blk_exit[b - 1];
+            need = in != start;
+            start = in;
+            s_flag = need;
+        }
+        __syncthreads();
+        if (!s_flag) return;
+        if (tid == 0) *changed = 1;
+    }
+    stage_block_words(sdata, words, b * DEC_BLOCK_WORDS, n_bytes);
+    load_decode_tables(tb, s_lut, s_long);
+    __syncthreads();
+
+    const uint64_t limit_rel = n_bytes * 8 - b * DEC_BLOCK_WORDS * 32;
+    for (;;) {
+        if (need) {
+            const SubResult r = walk_subsequence<false>(sdata, s_lut, s_long, tb.lut_bits, tb.n_long, tid, start, limit_rel, nullptr, 0, 0, 0);
+            exit_rel = r.exit_rel;
+            count = r.count;
+        }
+        s_exit[tid] = exit_rel;
+        __syncthreads();
+        need = false;
+        if (tid > 0 && live) {
+            const uint32_t in = s_exit[tid - 1];
+            need = in != start;
+            start = in;
+        }
+        if (!__syncthreads_or(need)) break;
+    }
+    if (live) sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
+    uint32_t total;
+    block_exclusive_scan(live ? count : 0u, scratch, &total);
+    if (tid == 0) blk_count[b] = total;
+    // exit of the last live subsequence of this workgroup
+    const uint64_t last_live = (n_subs - b * BLOCK >= BLOCK) ? BLOCK - 1 : (n_subs - b * BLOCK - 1);
+    if (tid == static_cast<int>(last_live)) blk_exit[b] = exit_rel;
+}
+
+// D2: single-workgroup exclusive scan of blk_count -> blk_off (u64), total at [n].
+__global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *__restrict__ blk_count, uint32_t n_blocks,
+                                                   unsigned long long *__restrict__ blk_off) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += 1024) {
+        const uint32_t i = c0 + tid;
+        const unsigned long long x = (i < n_blocks) ? blk_count[i] : 0ull;
+        const unsigned long long inc = wave_inclusive_scan64(x);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n_blocks) blk_off[i] = before + inc - x;
+        __syncthreads();
+        if (tid == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) blk_off[n_blocks] = carry_s;
+}
+
+// D3: decode every subsequence from its synchronised start and write the symbols.
+// Symbols are staged in LDS so that the workgroup's contiguous output range leaves
+// as 16-byte stores; stage byte j maps to out byte (o0 & ~15) + j.
+__global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict__ words, uint64_t n_bytes, uint64_t n_subs,
+                                                     DecodeTables tb, const uint32_t *__restrict__ sub_state,
+                                                     const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
+                                                     uint8_t *__restrict__ out) {
+    __shared__ uint32_t sdata[DEC_BLOCK_WORDS + 2];
+    __shared__ uint16_t s_lut[1 << DEC_LUT_BITS_MAX];
+    __shared__ uint32_t s_long[512];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[DEC_STAGE_BYTES];
+    __shared__ uint32_t scratch[4];
+    const int tid = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    const uint64_t o0 = blk_off[b];
+    if (o0 >= n_symbols) return;  // pad bits decoded past the declared length
+    const uint64_t sub_g = b * BLOCK + tid;
+    const bool live = sub_g < n_subs;
+    const uint32_t st = live ? sub_state[sub_g] : 0u;
+    const uint32_t start = st & 0xffu, count = live ? (st >> 16) : 0u;
+
+    stage_block_words(sdata, words, b * DEC_BLOCK_WORDS, n_bytes);
+    load_decode_tables(tb, s_lut, s_long);
+    uint32_t block_total;
+    const uint32_t my_off = block_exclusive_scan(count, scratch, &block_total);  // barrier inside covers the staging
+    __syncthreads();
+
+    uint64_t o1 = o0 + block_total;
+    if (o1 > n_symbols) o1 = n_symbols;
+    const uint32_t n_out = static_cast<uint32_t>(o1 - o0);
+    const uint32_t phase = static_cast<uint32_t>(o0 & 15);  // stage offset of the first symbol
+    const uint64_t limit_rel = n_bytes * 8 - b * DEC_BLOCK_WORDS * 32;
+    uint8_t *out_base = out + (o0 - phase);
+
+    // stage positions are `phase + symbol index`; windows of DEC_STAGE_BYTES of them
+    for (uint32_t win = 0; win < phase + n_out; win += DEC_STAGE_BYTES) {
+        const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
+        const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
+        if (live && my_lo < win_hi && my_hi > win)
+            walk_subsequence<true>(sdata, s_lut, s_long, tb.lut_bits, tb.n_long, tid, start, limit_rel, stage, my_lo, win, win_hi);
+        __syncthreads();
+        const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
+        for (uint32_t g = win + tid * 16; g < win_hi; g += BLOCK * 16) {
+            if (g >= lo_valid && g + 16 <= win_hi) {
+                *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(stage + (g - win));
+            } else {
+                for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = stage[k - win];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------
+// launch wrappers (plain C++ callable; everything is enqueued on `stream`)
+// --------------------------------------------------------------------------------
+static inline uint32_t hist_grid(uint32_t n_tiles) { return n_tiles < MAX_GRID ? n_tiles : MAX_GRID; }
+
+void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
+                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist) {
+    const uint32_t grid = hist_grid(n_tiles);
+    (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
+    hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist);
+    const uint32_t rgrid = grid < 64 ? grid : 64;
+    hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
+}
+
+uint32_t hist_rows(uint32_t n_tiles) { return hist_grid(n_tiles); }
+
+void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
+                      unsigned long long *tile_bits, unsigned long long base_bit, unsigned long long *tile_off, uint32_t *out32) {
+    uint32_t grid = (n_tiles + 3) / 4;
+    if (grid > MAX_GRID) grid = MAX_GRID;
+    hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, tile_bits, n_tiles, base_bit, tile_off, out32);
+}
+
+void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
+                   const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32) {
+    const uint32_t grid = hist_grid(n_tiles);
+    if (max_len > 32)
+        hipLaunchKernelGGL(k_encode_tiles_long, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+    else if (max_len <= 16)
+        hipLaunchKernelGGL(k_encode_tiles<4096>, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+    else
+        hipLaunchKernelGGL(k_encode_tiles<8192>, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+}
+
+void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
+                     const uint16_t *lut, const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, uint32_t iter,
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed) {
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
+    DecodeTables tb{lut, longc, lut_bits, n_long};
+    hipLaunchKernelGGL(k_dec_sync, dim3(n_blocks), dim3(BLOCK), 0, stream, words, n_bytes, first_bit, n_subs, tb, iter, sub_state, blk_exit, blk_count, changed);
+}
+
+void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *blk_off) {
+    hipLaunchKernelGGL(k_dec_scan, dim3(1), dim3(1024), 0, stream, blk_count, n_blocks, blk_off);
+}
+
+void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const uint16_t *lut,
+                      const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, const uint32_t *sub_state,
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out) {
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
+    DecodeTables tb{lut, longc, lut_bits, n_long};
+    hipLaunchKernelGGL(k_dec_write, dim3(n_blocks), dim3(BLOCK), 0, stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_symbols, out);
+}
+
+}  // namespace et

@@ -1,0 +1,159 @@
+/*
+ * entreepy_hip.h -- C ABI of libentreepy_hip.so: the MI355X (gfx950) Huffman
+ * encode/decode path that drops in for typio/entreepy's src/encode.zig and
+ * src/decode.zig.
+ *
+ * The reference has no FFI of its own; the seam is the pair of Zig functions
+ *     pub fn encode(allocator, text, out_writer, std_out, flags) !usize   (src/encode.zig:25)
+ *     pub fn decode(allocator, compressed_text, out_writer, std_out, flags) !usize (src/decode.zig:13)
+ * called from src/main.zig:202,204 and src/test.zig:15,26.  Each entry point below
+ * names the reference lines it replaces; INTEGRATION.md shows the Zig `extern fn`
+ * declarations a maintainer adds to bind them.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every function
+ * returns an et_status (0 == ET_OK); nothing aborts or prints.  An et_ctx owns one
+ * GPU's stream, workspaces and pinned staging and is NOT thread-safe; use one per
+ * thread/GPU.  Pointers named d_* are device (HBM) pointers on the ctx's GPU,
+ * everything else is host memory.
+ */
+#ifndef ENTREEPY_HIP_H
+#define ENTREEPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum et_status {
+    ET_OK = 0,
+    ET_ERR_EMPTY = 1,       /* error.QueueEmpty: empty input (queue.zig:28-30 via encode.zig:137-138) */
+    ET_ERR_NOMEM = 2,       /* error.OutOfMemory (encode.zig:254) */
+    ET_ERR_CAP = 3,         /* output buffer too small (writer error / error.NoSpaceLeft) */
+    ET_ERR_FORMAT = 4,      /* malformed .et stream (the reference performs no validation, main.zig:199) */
+    ET_ERR_HIP = 5,         /* HIP runtime failure; et_last_error() has the text */
+    ET_ERR_ARG = 6,         /* null/misaligned/out-of-range argument */
+    ET_ERR_UNSUPPORTED = 7  /* stream needs a feature outside the decoder's domain (code length > 32) */
+} et_status;
+
+/* The reference's `dictionary: [256]Code` (encode.zig:141-146) plus what its -d dump
+ * and header need.  Plain data; filled by et_build_codebook / et_parse_header. */
+typedef struct et_codebook {
+    uint32_t data[256];      /* Code.data: path bits, u32-truncated (encode.zig:142,181,195) */
+    uint8_t length[256];     /* Code.length: 0 == symbol absent (or dropped, 256-symbol quirk) */
+    uint8_t dfs_order[256];  /* leaf symbols in the order encode.zig:204-212 prints them */
+    uint32_t n_coded;        /* symbols with length > 0 */
+    uint32_t min_length;     /* shortest non-zero length (0 when n_coded == 0) */
+    uint32_t max_length;     /* longest length */
+} et_codebook;
+
+/* Wall-clock split of the last whole call, in milliseconds (device phases from HIP
+ * events on the ctx stream).  Replaces the -d "time taken" line (encode.zig:26-28). */
+typedef struct et_timings {
+    float hist_ms;      /* encode: byte histogram kernels */
+    float host_ms;      /* encode: D2H + tree/code build + H2D; decode: header parse + LUT build */
+    float scan_ms;      /* encode: tile bit totals + offset scan; decode: block count scan */
+    float body_ms;      /* encode: code scatter kernel; decode: symbol write kernel */
+    float sync_ms;      /* decode: self-synchronisation kernels */
+    float total_ms;     /* first to last event */
+    uint32_t sync_iters;/* decode: synchronisation launches */
+    uint32_t reserved;
+} et_timings;
+
+typedef struct et_ctx et_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------- */
+/* The reference call is stateless; a ctx amortises hipMalloc, pinned staging and
+ * stream creation across calls.  `device` is a HIP device ordinal. */
+int et_ctx_create(int device, et_ctx **ctx);
+void et_ctx_destroy(et_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * ctx's own.  NULL restores the own stream. */
+int et_ctx_set_stream(et_ctx *ctx, void *hip_stream);
+/* Pre-size workspaces for inputs of up to max_text_bytes so that no allocation
+ * happens inside a timed call. */
+int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes);
+/* Record per-phase HIP events (small overhead); off by default. */
+int et_ctx_enable_timing(et_ctx *ctx, int on);
+int et_last_timings(const et_ctx *ctx, et_timings *out);
+const char *et_last_error(const et_ctx *ctx);
+const char *et_strerror(int status);
+const char *et_version(void);
+
+/* ---- whole-call entry points (what the Zig shims bind) -------------------------- */
+/* encode.zig:253-254: the reference sizes its scratch as 7200 + text.len; same bound
+ * here (rounded up to a multiple of 16). */
+size_t et_encode_bound(size_t text_len);
+
+/* Replaces encode() (encode.zig:25-337) for write_output=true: histogram (:43-47),
+ * code construction (:54-214), header+dictionary (:253-299), body pack (:303-318).
+ * Writes the complete .et file image to out[0..*out_len).  ET_ERR_EMPTY for n == 0
+ * (the reference raises error.QueueEmpty). */
+int et_encode(et_ctx *ctx, const uint8_t *text, size_t n,
+              uint8_t *out, size_t cap, size_t *out_len);
+
+/* Replaces decode() (decode.zig:13-220).  `compressed` is the .et file MINUS its
+ * first 4 bytes, exactly what main.zig:204 / test.zig:26 pass.  Emits body_len
+ * symbols (header field, decode.zig:36-42), or fewer when the bitstream ends first. */
+int et_decode(et_ctx *ctx, const uint8_t *compressed, size_t len,
+              uint8_t *out, size_t cap, size_t *out_len);
+
+/* Code table of the ctx's most recent et_encode / et_encode_device (for the -d dump,
+ * encode.zig:204-212, which the reference prints from inside encode()). */
+int et_last_codebook(const et_ctx *ctx, et_codebook *out);
+
+/* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */
+int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols);
+
+/* Same two calls with input and output resident in HBM (benchmarks, pipelines).
+ * d_out must hold et_encode_bound(n) bytes / n_symbols (+16 slack) bytes. */
+int et_encode_device(et_ctx *ctx, const void *d_text, size_t n,
+                     void *d_out, size_t cap, size_t *out_len);
+int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t len,
+                     void *d_out, size_t cap, size_t *out_len);
+
+/* ---- staged entry points (sharded multi-GPU encode, tests) ------------------------ */
+/* encode.zig:43-47 on the GPU: 256 x u64 counts of d_text[0..n) into d_hist (device).
+ * Also leaves per-tile histograms in the ctx for a following et_encode_body_device
+ * on the SAME (d_text, n). */
+int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, void *d_hist256_u64);
+
+/* encode.zig:54-214 + queue.zig:9-43 on the host: sort, two-queue tree, codes.
+ * Bit-exact including the u8 book_index saturation (256 distinct symbols), the u32
+ * path truncation and single-symbol inputs.  ET_ERR_EMPTY when every count is 0. */
+int et_build_codebook(const uint64_t hist[256], et_codebook *cb);
+
+/* encode.zig:259-299: magic, version, D, low 32 bits of text_len, bit-packed
+ * dictionary, zero pad to a byte.  At most 4631 bytes. */
+int et_write_header(const et_codebook *cb, uint64_t text_len,
+                    uint8_t *out, size_t cap, size_t *header_len);
+
+/* Sum over s of hist[s] * length[s]: the body bit count of a shard, from its local
+ * histogram alone (no data pass). */
+int et_codebook_bits(const et_codebook *cb, const uint64_t hist[256], uint64_t *bits);
+
+/* encode.zig:303-315 on the GPU for one shard: pack the codes of d_text[0..n) into
+ * d_out as a MSB-first bitstream whose first bit lands at bit `start_bit` of d_out
+ * (d_out 4-byte aligned).  Every 32-bit word the shard touches is fully overwritten
+ * (bits outside [start_bit, *end_bit) in the first/last word become 0), so adjacent
+ * shards are concatenated by OR-ing their boundary bytes.  Requires the preceding
+ * et_histogram_device on the same (d_text, n). */
+int et_encode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n,
+                          void *d_out, size_t cap_bytes, uint64_t start_bit, uint64_t *end_bit);
+
+/* decode.zig:34-141 on the host: D, body length, dictionary.  *body_offset is the
+ * byte offset of the body inside `compressed` (decode.zig:156: 5 + global_pos). */
+int et_parse_header(const uint8_t *compressed, size_t len, et_codebook *cb,
+                    uint64_t *n_symbols, size_t *body_offset);
+
+/* decode.zig:143-203 on the GPU: decode up to n_symbols symbols from the bitstream
+ * d_body[0..body_bytes) beginning at bit `start_bit` (< 8) of d_body. */
+int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body,
+                          size_t body_bytes, uint32_t start_bit, uint64_t n_symbols,
+                          void *d_out, size_t cap, size_t *out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENTREEPY_HIP_H */

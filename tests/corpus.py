@@ -1,0 +1,59 @@
+"""Deterministic synthetic inputs shared by tests, smoke() and bench.py.
+
+None of the reference's benchmark corpora exist offline, so text-like streams are
+i.i.d. order-0 samples of the byte distribution of res/a_midsummer_nights_dream.txt
+(93 symbols, entropy ~4.69 bits/byte, no NUL, max code length 17).
+"""
+import os
+
+import numpy as np
+
+_RES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "res")
+
+
+def midsummer():
+    with open(os.path.join(_RES, "a_midsummer_nights_dream.txt"), "rb") as f:
+        return f.read()
+
+
+def midsummer_distribution():
+    h = np.bincount(np.frombuffer(midsummer(), dtype=np.uint8), minlength=256).astype(np.float64)
+    return h / h.sum()
+
+
+def text_like(n, seed):
+    """n bytes, order-0 samples of Midsummer's distribution (numpy Generator PCG64)."""
+    p = midsummer_distribution()
+    cdf = np.cumsum(p)
+    cdf[-1] = 1.0
+    rng = np.random.default_rng(seed)
+    return np.searchsorted(cdf, rng.random(n), side="right").astype(np.uint8)
+
+
+def tiled_midsummer(n):
+    t = np.frombuffer(midsummer(), dtype=np.uint8)
+    reps = (n + t.size - 1) // t.size
+    return np.tile(t, reps)[:n].copy()
+
+
+def uniform(n, seed, lo=0, hi=256):
+    return np.random.default_rng(seed).integers(lo, hi, size=n, dtype=np.uint8 if hi <= 256 else np.uint16).astype(np.uint8)
+
+
+def text_like_torch(n, seed, device):
+    """Same distribution generated on the device (bench sizes): torch.multinomial-free
+    inverse-CDF sampling with a seeded torch generator."""
+    import torch
+
+    p = torch.tensor(midsummer_distribution(), dtype=torch.float64, device=device)
+    cdf = torch.cumsum(p, 0).to(torch.float32)
+    cdf[-1] = 2.0
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    step = 1 << 26
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        u = torch.rand(m, generator=g, device=device, dtype=torch.float32)
+        out[s : s + m] = torch.searchsorted(cdf, u, right=True).clamp_(max=255).to(torch.uint8)
+    return out
