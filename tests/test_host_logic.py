@@ -1,0 +1,147 @@
+"""CPU: the product's host half (et_codebook.cpp through the C ABI) against the
+oracle, and the shape of the C ABI itself.  No GPU compute is called."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import entreepy_amd as E
+from entreepy_amd import _native as N
+from oracle import oracle as O
+from tests.conftest import ROOT
+
+
+def _same_tables(hist, text_len):
+    try:
+        od, ol, oo = O.build_dict(hist)
+    except O.OracleError:
+        with pytest.raises(E.EmptyInputError):
+            E.Codebook.from_histogram(hist)
+        return
+    cb = E.Codebook.from_histogram(hist)
+    assert (cb.data == od).all() and (cb.length == ol).all()
+    assert cb.dfs_order.tolist() == oo.tolist()
+    assert cb.header(text_len) == O.write_header(od, ol, text_len)
+    assert cb.bits(hist) == int((hist * ol.astype(np.uint64)).sum())
+
+
+def test_header_declares_what_the_library_exports():
+    """Every function include/entreepy_hip.h declares is exported, and the binding
+    declares the same set."""
+    with open(os.path.join(ROOT, "include", "entreepy_hip.h")) as f:
+        declared = set(re.findall(r"\b(et_[a-z0-9_]+)\s*\(", f.read()))
+    declared -= {"et_status"}
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", N.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (et_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    lib = N.lib()
+    assert b"gfx950" in lib.et_version()
+    assert lib.et_encode_bound(100) == 7312  # 7200 + n (encode.zig:253-254), rounded to 16
+
+
+def test_reference_fixtures_tables(res_files):
+    for text in res_files.values():
+        _same_tables(O.histogram(text), len(text))
+
+
+@pytest.mark.parametrize("mode", range(6))
+def test_random_histograms(mode):
+    rng = np.random.default_rng(100 + mode)
+    for _ in range(400):
+        k = int(rng.integers(0, 257))
+        hist = np.zeros(256, dtype=np.uint64)
+        idx = rng.choice(256, size=k, replace=False)
+        if mode == 0:
+            vals = rng.integers(1, 4, size=k)
+        elif mode == 1:
+            vals = rng.integers(1, 1000, size=k)
+        elif mode == 2:
+            vals = 2 ** rng.integers(0, 40, size=k)
+        elif mode == 3:
+            vals = np.ones(k)
+        elif mode == 4:
+            vals = rng.geometric(0.001, size=k)
+        else:
+            vals = rng.integers(1, 3, size=k) * 1000  # many ties
+        hist[idx] = np.asarray(vals, dtype=np.uint64)
+        _same_tables(hist, int(hist.sum() % (1 << 40)))
+
+
+def test_quirk_tables():
+    hist = np.arange(1, 257, dtype=np.uint64)
+    _same_tables(hist, 5)  # 256 distinct (Q1)
+    assert E.Codebook.from_histogram(hist).raw.n_coded == 255
+    one = np.zeros(256, dtype=np.uint64)
+    one[97] = 4
+    _same_tables(one, 4)  # single symbol (Q2)
+    assert E.Codebook.from_histogram(one).header(4).hex() == "e7c0de010000000004"
+    fib = [1, 1]
+    while len(fib) < 45:
+        fib.append(fib[-1] + fib[-2])
+    h = np.zeros(256, dtype=np.uint64)
+    h[10:55] = fib
+    _same_tables(h, int(h.sum()))  # code lengths up to 44 (Q3)
+    assert E.Codebook.from_histogram(h).raw.max_length == 44
+    _same_tables(O.histogram(b"abc"), (1 << 34) + 5)  # 32-bit length wrap (Q4)
+
+
+def test_parse_header_inverts_write_header(res_files):
+    for text in list(res_files.values()) + [bytes(range(1, 256)) * 2, b"ab", bytes([0, 1, 0, 2, 0, 0, 3])]:
+        et = O.encode(text)
+        cb, n, off = E.parse_header(et[4:])
+        od, ol, _ = O.build_dict(O.histogram(text))
+        assert n == len(text)
+        assert (cb.length == ol).all() and (cb.data[ol > 0] == od[ol > 0]).all()
+        assert off + 4 == len(O.write_header(od, ol, len(text)))
+
+
+def test_parse_header_rejects_malformed():
+    et = O.encode(b"hello world, hello huffman")
+    good = et[4:]
+    with pytest.raises(E.EntreepyError):
+        E.parse_header(good[:3])  # shorter than the fixed header
+    with pytest.raises(E.EntreepyError):
+        E.parse_header(good[:9])  # dictionary truncated
+    # two entries with the same code -> not prefix-free
+    bad = bytearray(good)
+    cb, n, off = E.parse_header(good)
+    dup = bytes([1]) + good[1:5] + bytes([ord("a"), 1, 0b00000000 | (ord("b") >> 1), ((ord("b") & 1) << 7) | 0, 0b10000000])
+    with pytest.raises(E.EntreepyError):
+        E.parse_header(dup)
+
+
+def test_single_symbol_stream_parses_as_empty():
+    cb, n, off = E.parse_header(bytes.fromhex("e7c0de010000000004")[4:])
+    assert n == 4 and off == 5 and cb.raw.n_coded == 0
+
+
+def test_gpu_calls_fail_loudly_without_a_device():
+    """No CPU fallback: with no GPU in the process every compute entry point reports
+    ET_ERR_HIP instead of computing something."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(E.EntreepyError) as ei:
+        E.Context(0)
+    assert ei.value.status == N.ET_ERR_HIP
+    with pytest.raises(E.EntreepyError):
+        E.encode(b"abc")
+
+
+def test_cli_surface_without_gpu(tmp_path):
+    """main.zig:45-67 help text and option errors do not need a device."""
+    exe = os.path.join(ROOT, "entreepy_amd", "entreepy")
+    out = subprocess.run([exe, "-h"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("Entreepy - Text compression tool\n\nUsage: entreepy [options] [command] [file] [command options]\n")
+    assert "    -o, --output    output file (default: [file].et or decoded_[file])\n" in out.stdout
+    assert subprocess.run([exe], capture_output=True, text=True).stdout == out.stdout  # main.zig:148-152
+    assert subprocess.run([exe, "--help"], capture_output=True, text=True).stdout == out.stdout
+    bad = subprocess.run([exe, "-x"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "invalid option: -x" in bad.stderr  # main.zig:116-118
+    bad = subprocess.run([exe, "zip", "f"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "invalid command: zip" in bad.stderr  # main.zig:131-134
