@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline metric on MI355X.
+
+A "step" is one pass of the hot path over one batch: encode the rank's text stream
+to a .et image (K1 histogram -> host code construction -> K2 scan -> K4 scatter) and
+decode that image back (D1 sync sweeps -> D2 scan -> D3 write), inputs resident in
+HBM.  Workload at N=1 (BASELINE.json metric): "text-1G", 2^30 bytes of order-0
+samples of res/a_midsummer_nights_dream.txt's byte distribution (no benchmark corpus
+exists offline).  N>1: every rank holds its own 2^30-byte shard of one
+N-GiB stream (weak scaling); the shards share one code table through an RCCL
+all-reduce of the histogram and land at their global bit offsets.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(sample_u8, budget_s=14.0):
+    """Oracle (kind "port": the Zig reference cannot be built here) on one host core,
+    on a prefix of the same stream sized to ~budget_s of CPU work."""
+    from oracle import oracle as O
+
+    probe = sample_u8[: 4 << 20]
+    t = time.perf_counter()
+    et = O.encode(probe)
+    O.decode(et[4:])
+    per_byte = (time.perf_counter() - t) / probe.size
+    n = int(min(sample_u8.size, max(probe.size, budget_s / per_byte)))
+    n -= n % 4096
+    data = sample_u8[:n]
+    t0 = time.perf_counter()
+    et = O.encode(data)
+    t1 = time.perf_counter()
+    back = O.decode(et[4:])
+    t2 = time.perf_counter()
+    assert back == data.tobytes()
+    return {
+        "value": round(n / (t2 - t0) / 1e9, 5),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {n >> 20} MiB of rank 0's text-1G stream, oracle encode+decode round trip "
+                  f"(encode {n / (t1 - t0) / 1e6:.1f} MB/s, decode {n / (t2 - t1) / 1e6:.1f} MB/s), 1 thread",
+    }
+
+
+def load_pmc_traffic(kernel):
+    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/pmc_latest.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bytes", type=int, default=int(os.environ.get("ET_BENCH_BYTES", 1 << 30)), help="text bytes per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import entreepy_amd as E
+    from entreepy_amd import sharded
+    from tests import corpus
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.bytes
+    text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev)
+    ctx = E.Context(local)
+    ctx.use_torch_stream()
+    ctx.reserve(n)
+    ctx.enable_timing(True)
+    enc = torch.zeros(E.encode_bound(n) + 64, dtype=torch.uint8, device=dev)
+    dec = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    pipe = sharded.ShardedCodec(ctx, dist.group.WORLD if world > 1 else None, dev)
+
+    phases = {"hist": 0.0, "enc_host": 0.0, "enc_scan": 0.0, "enc_body": 0.0, "dec_sync": 0.0, "dec_scan": 0.0, "dec_body": 0.0,
+              "enc_total": 0.0, "dec_total": 0.0, "sync_launches": 0, "exchange": 0.0}
+    state = {}
+
+    def step(record):
+        r = pipe.encode_shard(text, enc)
+        if record:
+            for k in ("hist", "enc_host", "enc_scan", "enc_body", "enc_total", "exchange"):
+                phases[k] += r["timings"][k]
+        m = pipe.decode_shard(enc, r, dec)
+        if record:
+            t = ctx.timings()
+            phases["dec_sync"] += t["sync_ms"]
+            phases["dec_scan"] += t["scan_ms"]
+            phases["dec_body"] += t["body_ms"]
+            phases["dec_total"] += t["total_ms"]
+            phases["sync_launches"] += t["sync_iters"]
+        state.update(r)
+        state["decoded"] = m
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    assert state["decoded"] == n and torch.equal(dec[:n], text), "round trip is not the identity"
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        K = args.steps
+        ms = {k: v / K for k, v in phases.items()}
+        m_bytes = state["body_bytes"]          # packed body bytes of this rank's shard
+        sync_launches = phases["sync_launches"] / K
+        kernels = {
+            # name: (ms per launch, algorithmic bytes per launch)
+            "k_hist_tiles": (ms["hist"], n),
+            "k_encode_tiles": (ms["enc_body"], n + m_bytes),
+            "k_dec_sync": (ms["dec_sync"] / max(sync_launches, 1), m_bytes),
+            "k_dec_write": (ms["dec_body"], m_bytes + n),
+        }
+        totals = {"k_hist_tiles": ms["hist"], "k_encode_tiles": ms["enc_body"], "k_dec_sync": ms["dec_sync"], "k_dec_write": ms["dec_body"]}
+        dominant = max(totals, key=totals.get)
+        d_ms, d_bytes = kernels[dominant]
+        achieved = d_bytes / (d_ms * 1e-3) / 1e9
+        enc_kernel_ms = ms["hist"] + ms["enc_scan"] + ms["enc_body"]
+        out = {
+            "metric": "GB/s encode+decode on 1 GiB text at 1/2/4/8 MI355X; % of HBM read peak",
+            "value": round(world * n / elapsed * K / 1e9, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"text-1G: {n} B per GPU, order-0 samples of a_midsummer_nights_dream.txt's byte distribution "
+                            f"(seed 0x5EED0004+rank), one step = encode to .et + decode back, HBM-resident",
+                "bytes_per_gpu": n,
+                "packed_bytes_per_gpu": m_bytes,
+                "sharding": "1 stream" if world == 1 else f"{world} contiguous shards of one stream, RCCL histogram all-reduce + bit-offset all-gather",
+                "value_definition": "text bytes taken through encode+decode per second, all GPUs",
+            },
+            "encode_GBps": round(world * n / (ms["enc_total"] * 1e-3) / 1e9, 2),
+            "decode_GBps": round(world * n / (ms["dec_total"] * 1e-3) / 1e9, 2),
+            "encode_hbm_frac": round((2 * n + m_bytes) / (enc_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "phase_ms": {k: round(v, 4) for k, v in ms.items()},
+            "roofline": {
+                "kernel": dominant,
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": load_pmc_traffic(dominant),
+                "ms_per_launch": round(d_ms, 4),
+                "algorithmic_bytes_per_launch": d_bytes,
+            },
+            "kernels": {k: {"ms_per_launch": round(v[0], 4), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] else None,
+                            "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if v[0] else None} for k, v in kernels.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(text[: min(n, 768 << 20)].cpu().numpy())
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,7 @@ SIGNATURES = {
     "et_write_header": (ctypes.c_int, [_cbp, _u64, _vp, _sz, _szp]),
     "et_codebook_bits": (ctypes.c_int, [_cbp, _vp, _u64p]),
     "et_encode_body_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _vp, _sz, _u64, _u64p]),
+    "et_encode_head_shard_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _vp, _sz, _vp, _sz, _u64p]),
     "et_parse_header": (ctypes.c_int, [_vp, _sz, _cbp, _u64p, _szp]),
     "et_decode_body_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, ctypes.c_uint32, _u64, _vp, _sz, _szp]),
 }

@@ -218,6 +218,14 @@ class Context:
                                              out.numel() * out.element_size(), int(start_bit), ctypes.byref(end)), self._h)
         return end.value
 
+    def encode_head_shard_device(self, codebook, text, out, header):
+        """Shard 0 of a sharded encode: file header followed by the shard's body."""
+        end = ctypes.c_uint64(0)
+        hb = np.frombuffer(header, dtype=np.uint8)
+        _check(N.lib().et_encode_head_shard_device(self._h, ctypes.byref(codebook.raw), text.data_ptr(), text.numel(), out.data_ptr(),
+                                                   out.numel() * out.element_size(), hb.ctypes.data, hb.size, ctypes.byref(end)), self._h)
+        return end.value
+
     def decode_body_device(self, codebook, body, n_symbols, out, start_bit=0):
         n = ctypes.c_size_t(0)
         _check(N.lib().et_decode_body_device(self._h, ctypes.byref(codebook.raw), body.data_ptr(), body.numel(), int(start_bit),

@@ -345,34 +345,72 @@ extern "C" int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, vo
         return ET_OK;
     }
     const Geometry g = make_geometry(d_text, n);
+    record(ctx, 0);
     ET_TRY(run_histogram(ctx, d_text, n, g));
+    record(ctx, 1);
     ET_HIP(hipMemcpyAsync(d_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->timing) {
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->tm = et_timings{};
+        ctx->tm.hist_ms = elapsed(ctx, 0, 1);
+    }
     return ET_OK;
 }
 
-extern "C" int et_encode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n, void *d_out, size_t cap_bytes,
-                                     uint64_t start_bit, uint64_t *end_bit) {
+namespace {
+
+int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n, void *d_out, size_t cap_bytes, uint64_t start_bit,
+                 const uint8_t *header, size_t header_len, uint64_t *end_bit) {
     if (!ctx || !cb || !d_out || !end_bit || (n && !d_text)) return ET_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(d_out) & 3) return fail(ctx, ET_ERR_ARG, "d_out must be 4-byte aligned");
+    if (header_len > HEADER_STAGE - 4) return fail(ctx, ET_ERR_ARG, "header too long");
+    DeviceGuard guard(ctx->device);
     if (n == 0) {
+        if (header_len) ET_HIP(hipMemcpyAsync(d_out, header, header_len, hipMemcpyHostToDevice, ctx->stream));
         *end_bit = start_bit;
         return ET_OK;
     }
     if (ctx->hist_text != d_text || ctx->hist_n != n)
-        return fail(ctx, ET_ERR_ARG, "et_encode_body_device needs et_histogram_device on the same (d_text, n) first");
-    DeviceGuard guard(ctx->device);
+        return fail(ctx, ET_ERR_ARG, "shard encode needs et_histogram_device on the same (d_text, n) first");
     ET_TRY(fetch_histogram(ctx));
-    ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned code-table staging may still feed an earlier call
+    ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned staging may still feed an earlier call
     uint64_t bits = 0;
     et_codebook_bits(cb, ctx->h_hist, &bits);
     const uint64_t end = start_bit + bits;
     if (((end + 31) / 32) * 4 > cap_bytes) return fail(ctx, ET_ERR_CAP, "body does not fit d_out");
+    if (header_len) {
+        std::memset(ctx->h_header, 0, HEADER_STAGE);
+        std::memcpy(ctx->h_header, header, header_len);
+    }
     Geometry g = make_geometry(d_text, n);
     g.rpt = ctx->hist_rpt;
     g.n_tiles = ctx->hist_tiles;
-    ET_TRY(run_body(ctx, cb, g, static_cast<uint32_t *>(d_out), start_bit, nullptr, 0, 2, 3));
+    if (bits == 0) {  // nothing but zero-length symbols: only the header, if any
+        if (header_len) ET_HIP(hipMemcpyAsync(d_out, ctx->h_header, (header_len + 3) & ~static_cast<size_t>(3), hipMemcpyHostToDevice, ctx->stream));
+        *end_bit = end;
+        return ET_OK;
+    }
+    ET_TRY(run_body(ctx, cb, g, static_cast<uint32_t *>(d_out), start_bit, header_len ? ctx->h_header : nullptr, header_len, 2, 3));
     *end_bit = end;
+    if (ctx->timing) {
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->tm.scan_ms = elapsed(ctx, 4, 2);
+        ctx->tm.body_ms = elapsed(ctx, 2, 3);
+    }
     return ET_OK;
+}
+
+}  // namespace
+
+extern "C" int et_encode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n, void *d_out, size_t cap_bytes,
+                                     uint64_t start_bit, uint64_t *end_bit) {
+    return encode_shard(ctx, cb, d_text, n, d_out, cap_bytes, start_bit, nullptr, 0, end_bit);
+}
+
+extern "C" int et_encode_head_shard_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n, void *d_out, size_t cap_bytes,
+                                           const uint8_t *header, size_t header_len, uint64_t *end_bit) {
+    if (!header || !header_len) return ET_ERR_ARG;
+    return encode_shard(ctx, cb, d_text, n, d_out, cap_bytes, static_cast<uint64_t>(header_len) * 8, header, header_len, end_bit);
 }
 
 extern "C" int et_encode_device(et_ctx *ctx, const void *d_text, size_t n, void *d_out, size_t cap, size_t *out_len) {

@@ -1,0 +1,162 @@
+"""One stream sharded by contiguous chunk across the GPUs of a node (one process per GPU).
+
+Encode has exactly one exchange step: the byte histogram.  Every rank
+  1. histograms its chunk on its GPU (K1),
+  2. all-gathers the 256 x u64 local histograms (RCCL over xGMI; 2 KiB per rank --
+     latency-bound, one collective).  The sum is the global histogram the reference
+     computes in encode.zig:43-47; the individual rows give every shard's body bit
+     count as sum(hist_r * length) with no further data pass or collective,
+  3. builds the same code table from the same global histogram (deterministic host
+     code, et_build_codebook), so no table broadcast is needed,
+  4. packs its chunk at its global bit offset (K2 + K4).  Rank r's piece covers file
+     words [S_r // 32, ceil(S_{r+1} / 32)); a word two ranks share is completed by
+     OR-ing the later rank's first word into the earlier rank's last word (4 bytes
+     per rank, second tiny collective).
+The file then exists as per-rank pieces resident in HBM; `gather_file` concatenates
+them on rank 0 (used by tests and the CLI, not part of the timed step).
+
+The collectives go through torch.distributed (backend "nccl" == RCCL on ROCm; "gloo"
+in the CPU tests, where a fake compute backend stands in for the GPU).
+"""
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .codec import Codebook
+
+
+def plan_shards(hists):
+    """hists: uint64 [world, 256] local histograms ->
+    (codebook, header bytes, start_bits[world + 1]) with start_bits measured from bit 0
+    of the FILE (header included)."""
+    hists = np.ascontiguousarray(hists, dtype=np.uint64)
+    total = hists.sum(axis=0, dtype=np.uint64)
+    cb = Codebook.from_histogram(total)  # raises EmptyInputError when every shard is empty (encode.zig:137-138)
+    header = cb.header(int(total.sum()))
+    starts = [8 * len(header)]
+    for h in hists:
+        starts.append(starts[-1] + cb.bits(h))
+    return cb, header, starts
+
+
+def piece_words(starts, r):
+    """File words [lo, hi) held by rank r's local buffer."""
+    lo = 0 if r == 0 else starts[r] // 32
+    hi = (starts[r + 1] + 31) // 32
+    return lo, max(hi, lo)
+
+
+def owned_words(starts, r):
+    """File words rank r contributes to the concatenation: a word shared by several
+    ranks belongs to the first of them."""
+    lo = 0 if r == 0 else (starts[r] + 31) // 32
+    hi = (starts[r + 1] + 31) // 32
+    return lo, max(hi, lo)
+
+
+class ShardedCodec:
+    def __init__(self, ctx, group, device):
+        self.ctx = ctx
+        self.group = group
+        self.device = device
+        self.world = dist.get_world_size(group) if group is not None else 1
+        self.rank = dist.get_rank(group) if group is not None else 0
+        self.hist = torch.zeros(256, dtype=torch.int64, device=device)
+        self.all_hists = torch.zeros(self.world * 256, dtype=torch.int64, device=device)
+        self.first_words = torch.zeros(self.world, dtype=torch.int32, device=device)
+        self._hdr_len = {}
+
+    # ------------------------------------------------------------------ encode
+    def encode_shard(self, text, enc):
+        """text: this rank's chunk (uint8 device tensor); enc: uint8 device buffer of
+        encode_bound(len) + 64 bytes, 16-byte aligned.  Returns the layout dict
+        decode_shard / gather_file need."""
+        n = text.numel()
+        ctx = self.ctx
+        if self.group is None:
+            et_len = ctx.encode_device(text, enc)
+            t = ctx.timings()
+            hdr = self._hdr_len.get(et_len)
+            if hdr is None:
+                cbk, _, off = _parse_device_header(enc, et_len)
+                hdr = self._hdr_len[et_len] = off + 4
+            return {"world": 1, "n": n, "et_len": et_len, "header_len": hdr, "body_bytes": et_len - hdr,
+                    "timings": {"hist": t["hist_ms"], "enc_host": t["host_ms"], "enc_scan": t["scan_ms"], "enc_body": t["body_ms"],
+                                "enc_total": t["total_ms"], "exchange": 0.0}}
+
+        t_begin = time.perf_counter()
+        ctx.histogram_device(text, self.hist)
+        hist_ms = ctx.timings()["hist_ms"]
+        t_x0 = time.perf_counter()
+        dist.all_gather_into_tensor(self.all_hists, self.hist, group=self.group)
+        hists = self.all_hists.view(self.world, 256).cpu().numpy().astype(np.uint64)
+        t_x1 = time.perf_counter()
+        cb, header, starts = plan_shards(hists)
+        t_h1 = time.perf_counter()
+        r = self.rank
+        if r == 0:
+            end = ctx.encode_head_shard_device(cb, text, enc, header)
+            local_start = starts[0]
+        else:
+            local_start = starts[r] % 32
+            end = ctx.encode_body_device(cb, text, enc, local_start)
+        assert end - local_start == starts[r + 1] - starts[r]
+        t = ctx.timings()
+        # complete the words shared with later ranks
+        t_x2 = time.perf_counter()
+        lo, hi = piece_words(starts, r)
+        self.first_words.zero_()
+        mine = enc[:4].view(torch.int32)
+        dist.all_gather_into_tensor(self.first_words, mine.clone(), group=self.group)
+        if hi > lo:
+            last = hi - 1
+            for q in range(r + 1, self.world):
+                if starts[q] // 32 == last and starts[q + 1] > starts[q]:
+                    w = enc[(last - lo) * 4 : (last - lo) * 4 + 4].view(torch.int32)
+                    w |= self.first_words[q : q + 1]
+        if enc.is_cuda:
+            torch.cuda.synchronize(self.device)
+        t_end = time.perf_counter()
+        return {"world": self.world, "n": n, "codebook": cb, "header_len": len(header) if r == 0 else 0, "starts": starts,
+                "local_start_bit": local_start, "end_bit": end, "body_bytes": (starts[r + 1] - starts[r] + 7) // 8,
+                "timings": {"hist": hist_ms, "enc_host": (t_h1 - t_x1) * 1e3, "enc_scan": t.get("scan_ms", 0.0), "enc_body": t.get("body_ms", 0.0),
+                            "enc_total": (t_end - t_begin) * 1e3, "exchange": (t_x1 - t_x0 + t_end - t_x2) * 1e3}}
+
+    # ------------------------------------------------------------------ decode
+    def decode_shard(self, enc, layout, dec):
+        """Decode this rank's piece back into dec; returns the symbol count.  With one
+        GPU this is the reference's decode(file[4..]) (header parsed from the stream);
+        with several, every rank decodes its own bit range [S_r, S_{r+1}) using the
+        offsets the encode step produced (an in-memory pipeline, not a cold .et read)."""
+        ctx = self.ctx
+        if layout["world"] == 1:
+            return ctx.decode_device(enc[4 : layout["et_len"]], dec)
+        start = layout["local_start_bit"]
+        byte0 = start // 8
+        byte1 = (layout["end_bit"] + 7) // 8
+        return ctx.decode_body_device(layout["codebook"], enc[byte0:byte1], layout["n"], dec, start % 8)
+
+    # ------------------------------------------------------------------ concat
+    def gather_file(self, enc, layout):
+        """Bit-offset-adjusted concatenation on rank 0 -> bytes (None elsewhere)."""
+        if layout["world"] == 1:
+            return enc[: layout["et_len"]].cpu().numpy().tobytes()
+        starts, r = layout["starts"], self.rank
+        lo, _ = piece_words(starts, r)
+        olo, ohi = owned_words(starts, r)
+        mine = enc[(olo - lo) * 4 : (ohi - lo) * 4].cpu()
+        pieces = [None] * self.world
+        dist.all_gather_object(pieces, mine.numpy().tobytes(), group=self.group)
+        if r != 0:
+            return None
+        image = b"".join(pieces)
+        return image[: (starts[-1] + 7) // 8]
+
+
+def _parse_device_header(enc, et_len):
+    from .codec import parse_header
+
+    head = enc[4 : min(et_len, 8192)].cpu().numpy()
+    return parse_header(head)

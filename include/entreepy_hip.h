@@ -142,6 +142,13 @@ int et_codebook_bits(const et_codebook *cb, const uint64_t hist[256], uint64_t *
 int et_encode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n,
                           void *d_out, size_t cap_bytes, uint64_t start_bit, uint64_t *end_bit);
 
+/* Same, for the shard that also carries the file header (rank 0): header[0..header_len)
+ * is written to d_out[0..header_len) and the body starts right after it
+ * (start bit = 8 * header_len, encode.zig:299-303). */
+int et_encode_head_shard_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n,
+                                void *d_out, size_t cap_bytes, const uint8_t *header, size_t header_len,
+                                uint64_t *end_bit);
+
 /* decode.zig:34-141 on the host: D, body length, dictionary.  *body_offset is the
  * byte offset of the body inside `compressed` (decode.zig:156: 5 + global_pos). */
 int et_parse_header(const uint8_t *compressed, size_t len, et_codebook *cb,
