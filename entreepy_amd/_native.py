@@ -49,7 +49,9 @@ SIGNATURES = {
     "et_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "et_ctx_destroy": (None, [_vp]),
     "et_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "et_ctx_use_own_stream": (ctypes.c_int, [_vp]),
     "et_ctx_reserve": (ctypes.c_int, [_vp, _sz]),
+    "et_ctx_set_tile_rounds": (ctypes.c_int, [_vp, ctypes.c_uint32]),
     "et_ctx_enable_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "et_last_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     "et_last_codebook": (ctypes.c_int, [_vp, _cbp]),

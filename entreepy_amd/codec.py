@@ -158,7 +158,10 @@ class Context:
     # -- plumbing ---------------------------------------------------------------
     def use_stream(self, hip_stream):
         """Run on a caller-owned stream, e.g. torch.cuda.current_stream().cuda_stream."""
-        _check(N.lib().et_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream) if hip_stream else None), self._h)
+        _check(N.lib().et_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream)), self._h)
+
+    def use_own_stream(self):
+        _check(N.lib().et_ctx_use_own_stream(self._h), self._h)
 
     def use_torch_stream(self):
         import torch
@@ -167,6 +170,10 @@ class Context:
 
     def reserve(self, max_text_bytes):
         _check(N.lib().et_ctx_reserve(self._h, int(max_text_bytes)), self._h)
+
+    def set_tile_rounds(self, rounds):
+        """Force the encode tile to rounds x 4 KiB (0 = size-based).  Test/tuning knob."""
+        _check(N.lib().et_ctx_set_tile_rounds(self._h, int(rounds)), self._h)
 
     def enable_timing(self, on=True):
         _check(N.lib().et_ctx_enable_timing(self._h, int(bool(on))), self._h)

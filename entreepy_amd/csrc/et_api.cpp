@@ -36,6 +36,7 @@ struct et_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool timing = false;
+    uint32_t force_rpt = 0;
     std::string err;
 
     // encode workspaces
@@ -128,7 +129,7 @@ struct Geometry {
     uint32_t rpt, n_tiles;
 };
 
-Geometry make_geometry(const void *d_text, size_t n) {
+Geometry make_geometry(const et_ctx *ctx, const void *d_text, size_t n) {
     Geometry g;
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_text);
     g.base = reinterpret_cast<const uint8_t *>(a & ~static_cast<uintptr_t>(15));
@@ -137,6 +138,7 @@ Geometry make_geometry(const void *d_text, size_t n) {
     // Aim for >= 8192 tiles (32 per CU) before growing the tile towards 64 KiB.
     uint32_t rpt = 1;
     while (rpt < et::MAX_ROUNDS_PER_TILE && g.hi / (static_cast<uint64_t>(rpt) * et::ROUND_BYTES) > 8192) rpt <<= 1;
+    if (ctx && ctx->force_rpt) rpt = ctx->force_rpt;
     g.rpt = rpt;
     const uint64_t tile_bytes = static_cast<uint64_t>(rpt) * et::ROUND_BYTES;
     g.n_tiles = static_cast<uint32_t>((g.hi + tile_bytes - 1) / tile_bytes);
@@ -275,7 +277,7 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
 extern "C" void et_ctx_destroy(et_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->len_table,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->longc, &ctx->flag,
                       &ctx->io_in, &ctx->io_out};
@@ -292,7 +294,21 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
 
 extern "C" int et_ctx_set_stream(et_ctx *ctx, void *hip_stream) {
     if (!ctx) return ET_ERR_ARG;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return ET_OK;
+}
+
+extern "C" int et_ctx_use_own_stream(et_ctx *ctx) {
+    if (!ctx) return ET_ERR_ARG;
+    ctx->stream = ctx->own_stream;
+    return ET_OK;
+}
+
+extern "C" int et_ctx_set_tile_rounds(et_ctx *ctx, uint32_t rounds) {
+    if (!ctx) return ET_ERR_ARG;
+    if (rounds > et::MAX_ROUNDS_PER_TILE || (rounds & (rounds - 1))) return ET_ERR_ARG;
+    ctx->force_rpt = rounds;
+    ctx->hist_text = nullptr;  // tile histograms of another geometry are stale
     return ET_OK;
 }
 
@@ -318,8 +334,8 @@ extern "C" int et_last_codebook(const et_ctx *ctx, et_codebook *out) {
 extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     if (!ctx) return ET_ERR_ARG;
     DeviceGuard guard(ctx->device);
-    const Geometry g = make_geometry(reinterpret_cast<const void *>(static_cast<uintptr_t>(15)), max_text_bytes);
-    ET_TRY(ensure_encode_ws(ctx, g.n_tiles + 1));
+    const Geometry g = make_geometry(nullptr, reinterpret_cast<const void *>(static_cast<uintptr_t>(15)), max_text_bytes);
+    ET_TRY(ensure_encode_ws(ctx, g.n_tiles + 1));  // size-based geometry; a forced smaller tile grows on demand
     // decode: the body is at most ~max_text_bytes (+ header) bytes
     const uint64_t n_subs = (static_cast<uint64_t>(max_text_bytes) + 8192) * 8 / et::SUB_BITS + 2;
     const uint64_t n_blocks = n_subs / et::BLOCK + 2;
@@ -344,7 +360,7 @@ extern "C" int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, vo
         ctx->hist_text = nullptr;
         return ET_OK;
     }
-    const Geometry g = make_geometry(d_text, n);
+    const Geometry g = make_geometry(ctx, d_text, n);
     record(ctx, 0);
     ET_TRY(run_histogram(ctx, d_text, n, g));
     record(ctx, 1);
@@ -382,7 +398,7 @@ int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t 
         std::memset(ctx->h_header, 0, HEADER_STAGE);
         std::memcpy(ctx->h_header, header, header_len);
     }
-    Geometry g = make_geometry(d_text, n);
+    Geometry g = make_geometry(ctx, d_text, n);
     g.rpt = ctx->hist_rpt;
     g.n_tiles = ctx->hist_tiles;
     if (bits == 0) {  // nothing but zero-length symbols: only the header, if any
@@ -419,7 +435,7 @@ extern "C" int et_encode_device(et_ctx *ctx, const void *d_text, size_t n, void 
     if (reinterpret_cast<uintptr_t>(d_out) & 15) return fail(ctx, ET_ERR_ARG, "d_out must be 16-byte aligned");
     if (cap < et_encode_bound(n)) return fail(ctx, ET_ERR_CAP, "cap < et_encode_bound(n)");
     DeviceGuard guard(ctx->device);
-    const Geometry g = make_geometry(d_text, n);
+    const Geometry g = make_geometry(ctx, d_text, n);
     record(ctx, 0);
     ET_TRY(run_histogram(ctx, d_text, n, g));
     record(ctx, 1);

@@ -69,11 +69,16 @@ typedef struct et_ctx et_ctx;
 int et_ctx_create(int device, et_ctx **ctx);
 void et_ctx_destroy(et_ctx *ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * ctx's own.  NULL restores the own stream. */
+ * ctx's own.  NULL is HIP's default (null) stream, as everywhere in HIP. */
 int et_ctx_set_stream(et_ctx *ctx, void *hip_stream);
+/* Back to the non-blocking stream the ctx created for itself. */
+int et_ctx_use_own_stream(et_ctx *ctx);
 /* Pre-size workspaces for inputs of up to max_text_bytes so that no allocation
  * happens inside a timed call. */
 int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes);
+/* Tuning/test knob: force the encode tile to `rounds` x 4 KiB (1, 2, 4, 8 or 16);
+ * 0 restores the size-based choice.  Results never depend on it. */
+int et_ctx_set_tile_rounds(et_ctx *ctx, uint32_t rounds);
 /* Record per-phase HIP events (small overhead); off by default. */
 int et_ctx_enable_timing(et_ctx *ctx, int on);
 int et_last_timings(const et_ctx *ctx, et_timings *out);

@@ -245,3 +245,27 @@ def test_virtual_shards_concat(ctx, shards):
         file_img[base_byte : base_byte + piece.size] |= piece
         bit += end - local_start
     assert file_img[: (bit + 7) // 8].tobytes() == want
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("n", [70001, (3 << 20) + 77])
+def test_every_tile_geometry(ctx, rounds, n):
+    """Tiles of 1..16 rounds (the size-based choice reaches 16 only at ~1 GiB)."""
+    ctx.set_tile_rounds(rounds)
+    try:
+        _roundtrip(ctx, corpus.text_like(n, seed=rounds * 1000 + 7))
+        _roundtrip(ctx, corpus.uniform(n // 3, rounds, 1, 256))
+    finally:
+        ctx.set_tile_rounds(0)
+
+
+def test_grid_stride_and_multi_round_tiles(ctx):
+    """48 MiB: more tiles than the 2048-workgroup grid and 2-round tiles by size."""
+    import hashlib
+
+    O = _oracle()
+    data = corpus.text_like(48 << 20, 99)
+    got = ctx.encode(data)
+    want = O.encode(data)
+    assert hashlib.sha256(got).digest() == hashlib.sha256(want).digest() and got == want
+    assert ctx.decode(got[4:]) == data.tobytes()
