@@ -9,7 +9,6 @@ namespace et {
 constexpr int BLOCK = 256;                    // threads per workgroup: 4 wavefronts of 64
 constexpr uint32_t ROUND_BYTES = BLOCK * 16;  // one 16-byte load per lane
 constexpr uint32_t MAX_ROUNDS_PER_TILE = 16;  // tile <= 64 KiB (u32 tile counters, u32 bit cursors)
-constexpr int HIST_REP = 4;                   // lane-interleaved counter replicas per wavefront
 constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-stride beyond
 
 constexpr uint32_t SUB_BITS = 256;                             // decode: bits per lane subsequence

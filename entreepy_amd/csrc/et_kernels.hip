@@ -99,24 +99,27 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t *__restrict__ base, ui
 }
 
 // --------------------------------------------------------------------------------
-// K1: byte histogram with per-wavefront LDS privatisation
+// K1: byte histogram, LDS-privatised per lane bank
 // --------------------------------------------------------------------------------
-// LDS layout [wave][bin][HIST_REP] u32: every wavefront owns a private set of
-// counters, and inside it HIST_REP lane-interleaved replicas (replica = lane &
-// (HIST_REP-1)) split the same-address ds_add serialisation that skewed text causes.
-// Bank of a counter = (bin * HIST_REP + rep) mod 32, so the 32 lanes of a half-wave
-// spread over all banks.  Counters are u32 (a tile is at most 64 KiB); tile totals
-// go out as u32, workgroup totals as u64.
+// LDS layout [bin][32] u32, shared by the workgroup's 4 wavefronts: lane l adds to
+// replica l & 31 of its symbol's bin, i.e. to LDS bank l & 31 whatever the symbol.
+// A ds_add_u32 wave-instruction is served in two half-waves of 32 lanes, so within
+// a half every lane hits its own bank: no bank conflicts and no same-address
+// serialisation, however skewed the text.  (Per-wavefront private copies would only
+// multiply the LDS footprint: LDS atomics from different wavefronts never overlap in
+// time on the one LDS pipe of a CU.)  32 KiB per workgroup -> 5 workgroups per CU.
+// Counters are u32 (a tile is at most 64 KiB); tile totals go out as u32,
+// workgroup totals as u64.
 __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
                                                       uint32_t rounds_per_tile, uint32_t n_tiles,
                                                       uint32_t *__restrict__ tile_hist,
                                                       unsigned long long *__restrict__ block_hist) {
-    __shared__ __attribute__((aligned(16))) uint32_t sh[4 * 256 * HIST_REP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 4 * 256 * HIST_REP; i += BLOCK) sh[i] = 0;
+    __shared__ __attribute__((aligned(16))) uint32_t sh[256 * 32];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 256 * 32; i += BLOCK) sh[i] = 0;
     __syncthreads();
 
-    uint32_t *mine = sh + wave * 256 * HIST_REP + (lane & (HIST_REP - 1));
+    uint32_t *mine = sh + (tid & 31);
     unsigned long long acc = 0;  // thread `tid` owns bin `tid` of the workgroup total
     const uint64_t tile_bytes = static_cast<uint64_t>(rounds_per_tile) * ROUND_BYTES;
 
@@ -133,26 +136,27 @@ __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict_
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         const uint32_t sym = (cur.w[d] >> (8 * b)) & 0xffu;
-                        atomicAdd(mine + sym * HIST_REP, 1u);  // ds_add_u32, no return
+                        atomicAdd(mine + sym * 32, 1u);  // ds_add_u32, no return
                     }
                 }
             } else if (cur.valid) {
                 for (int k = 0; k < 16; ++k)
-                    if (cur.valid & (1u << k)) atomicAdd(mine + ((cur.w[k >> 2] >> (8 * (k & 3))) & 0xffu) * HIST_REP, 1u);
+                    if (cur.valid & (1u << k)) atomicAdd(mine + ((cur.w[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32, 1u);
             }
             cur = nxt;
         }
         __syncthreads();
-        // Tile flush: thread = bin; sum the 4 wavefront copies x HIST_REP replicas.
+        // Tile flush: thread = bin; sum (and clear) its 32 replicas, 16 bytes at a time.
+        // Rotating the start by the bin keeps the 16-lane groups of ds_read_b128 on
+        // different bank quads.
         uint32_t total = 0;
+        uint4 *row = reinterpret_cast<uint4 *>(sh + tid * 32);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t *p = sh + (w * 256 + tid) * HIST_REP;
-#pragma unroll
-            for (int r = 0; r < HIST_REP; ++r) {
-                total += p[r];
-                p[r] = 0;
-            }
+        for (int q = 0; q < 8; ++q) {
+            const int j = (q + tid) & 7;
+            const uint4 v = row[j];
+            total += v.x + v.y + v.z + v.w;
+            row[j] = make_uint4(0, 0, 0, 0);
         }
         tile_hist[static_cast<uint64_t>(t) * 256 + tid] = total;
         acc += total;
@@ -670,7 +674,7 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
     const uint32_t grid = hist_grid(n_tiles);
     if (max_len > 32)
         hipLaunchKernelGGL(k_encode_tiles_long, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
-    else if (max_len <= 16)
+    else if (max_len <= 31)  // a round emits at most 4096 * 31 / 32 + 2 words: fits a 4096-word ring
         hipLaunchKernelGGL(k_encode_tiles<4096>, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
     else
         hipLaunchKernelGGL(k_encode_tiles<8192>, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
