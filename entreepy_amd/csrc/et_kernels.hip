@@ -125,25 +125,31 @@ __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict_
 
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(tid) * 16;
-        Chunk cur = load_chunk(base, t0, lo, hi);
-        for (uint32_t r = 0; r < rounds_per_tile; ++r) {
-            Chunk nxt;
-            nxt.valid = 0;
-            if (r + 1 < rounds_per_tile) nxt = load_chunk(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi);
-            if (cur.valid == 0xffffu) {
+        // Four 16-byte loads in flight per lane: the kernel is latency-bound on HBM,
+        // not on the (conflict-free) LDS atomics.
+        for (uint32_t r0 = 0; r0 < rounds_per_tile; r0 += 4) {
+            Chunk c[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const uint32_t sym = (cur.w[d] >> (8 * b)) & 0xffu;
-                        atomicAdd(mine + sym * 32, 1u);  // ds_add_u32, no return
-                    }
-                }
-            } else if (cur.valid) {
-                for (int k = 0; k < 16; ++k)
-                    if (cur.valid & (1u << k)) atomicAdd(mine + ((cur.w[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32, 1u);
+            for (int u = 0; u < 4; ++u) {
+                c[u].valid = 0;
+                if (r0 + u < rounds_per_tile) c[u] = load_chunk(base, t0 + static_cast<uint64_t>(r0 + u) * ROUND_BYTES, lo, hi);
             }
-            cur = nxt;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c[u].valid == 0xffffu) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const uint32_t sym = (c[u].w[d] >> (8 * b)) & 0xffu;
+                            atomicAdd(mine + sym * 32, 1u);  // ds_add_u32, no return
+                        }
+                    }
+                } else if (c[u].valid) {
+                    for (int k = 0; k < 16; ++k)
+                        if (c[u].valid & (1u << k)) atomicAdd(mine + ((c[u].w[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32, 1u);
+                }
+            }
         }
         __syncthreads();
         // Tile flush: thread = bin; sum (and clear) its 32 replicas, 16 bytes at a time.
@@ -286,14 +292,30 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
             if (r + 1 < rounds_per_tile) nxt = load_chunk(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi);
 
             uint32_t code[16], len[16];
-            uint32_t tot = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint2 e = tab[(cur.w[k >> 2] >> (8 * (k & 3))) & 0xffu];
-                const bool ok = (cur.valid >> k) & 1u;
-                code[k] = ok ? e.x : 0u;
-                len[k] = ok ? e.y : 0u;
-                tot += len[k];
+                code[k] = e.x;
+                len[k] = e.y;
+            }
+            if (cur.valid != 0xffffu) {  // first/last chunk of the stream: bytes outside it carry no bits
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (!((cur.valid >> k) & 1u)) code[k] = len[k] = 0;
+            }
+            // Neighbouring symbols are merged into one piece of la + lb bits before the
+            // append step; a pair only fails to fit 32 bits when two codes of 17+ bits
+            // meet, which for Huffman codes of real text is a < 1e-9 event per pair.
+            uint32_t pcode[8], plen[8];
+            uint32_t tot = 0;
+            bool wide = false;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t la = len[2 * p];
+                plen[p] = la + len[2 * p + 1];
+                pcode[p] = code[2 * p] | (code[2 * p + 1] >> (la & 31u));  // la == 32 with lb > 0 is `wide`
+                wide |= plen[p] > 32;
+                tot += plen[p];
             }
             uint32_t round_total;
             const uint32_t excl = block_exclusive_scan(tot, scratch[r & 1], &round_total);
@@ -301,15 +323,29 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
             uint32_t pos = run + excl;
             uint32_t w = pos >> 5, fill = pos & 31;
             unsigned long long acc = 0;
+            if (!__any(wide)) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                acc |= static_cast<unsigned long long>(code[k]) << (32 - fill);
-                fill += len[k];
-                if (fill >= 32) {
-                    atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
-                    acc <<= 32;
-                    fill -= 32;
-                    ++w;
+                for (int p = 0; p < 8; ++p) {
+                    acc |= static_cast<unsigned long long>(pcode[p]) << (32 - fill);
+                    fill += plen[p];
+                    if (fill >= 32) {
+                        atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
+                        acc <<= 32;
+                        fill -= 32;
+                        ++w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    acc |= static_cast<unsigned long long>(code[k]) << (32 - fill);
+                    fill += len[k];
+                    if (fill >= 32) {
+                        atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
+                        acc <<= 32;
+                        fill -= 32;
+                        ++w;
+                    }
                 }
             }
             if (fill) atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
