@@ -16,6 +16,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,6 +29,7 @@ struct DevBuf {
 };
 
 constexpr size_t HEADER_STAGE = 8192;  // >= 4631-byte worst-case header, padded
+constexpr size_t SUB_TABLE_BYTES = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) << et::DEC_SUB_BITS_MAX) * sizeof(uint16_t) + 64;  // + slack for 16-byte rounded copies
 
 }  // namespace
 
@@ -37,12 +39,13 @@ struct et_ctx {
     hipStream_t stream = nullptr;
     bool timing = false;
     uint32_t force_rpt = 0;
+    uint32_t lut_bits_max = et::DEC_LUT_BITS_DEFAULT;
     std::string err;
 
     // encode workspaces
     DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, len_table;
     // decode workspaces
-    DevBuf sub_state, blk_exit, blk_count, blk_off, lut, longc, flag;
+    DevBuf sub_state, blk_exit, blk_count, blk_off, lut, longc, subt, flag;
     // staging for the host-pointer entry points
     DevBuf io_in, io_out;
 
@@ -51,8 +54,9 @@ struct et_ctx {
     uint32_t *h_enc = nullptr;      // 512 ({code,len} x 256)
     uint32_t *h_len = nullptr;      // 256
     uint8_t *h_header = nullptr;    // HEADER_STAGE
-    uint16_t *h_lut = nullptr;      // 1 << DEC_LUT_BITS_MAX
+    uint32_t *h_lut = nullptr;      // 1 << DEC_LUT_BITS_MAX
     uint32_t *h_long = nullptr;     // 512
+    uint16_t *h_sub = nullptr;      // DEC_SUB_TABLES_MAX << DEC_SUB_BITS_MAX
     uint64_t *h_scalar = nullptr;   // 4 (flag / totals)
 
     // link between et_histogram_device and et_encode_body_device
@@ -254,6 +258,10 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     et_ctx *ctx = new (std::nothrow) et_ctx();
     if (!ctx) return ET_ERR_NOMEM;
     ctx->device = device;
+    if (const char *env = std::getenv("ET_DEC_LUT_BITS")) {  // tuning knob: first-level decode table size
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 8 && v <= static_cast<long>(et::DEC_LUT_BITS_MAX)) ctx->lut_bits_max = static_cast<uint32_t>(v);
+    }
     DeviceGuard guard(device);
     bool ok = guard.ok;
     ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
@@ -262,8 +270,9 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_len), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), sizeof(uint16_t) << et::DEC_LUT_BITS_MAX) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_long), 512 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_sub), SUB_TABLE_BYTES) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 4 * sizeof(uint64_t)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
@@ -279,11 +288,11 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->len_table,
-                      &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->longc, &ctx->flag,
+                      &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->longc, &ctx->subt, &ctx->flag,
                       &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
-    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_len, ctx->h_header, ctx->h_lut, ctx->h_long, ctx->h_scalar};
+    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_len, ctx->h_header, ctx->h_lut, ctx->h_long, ctx->h_sub, ctx->h_scalar};
     for (void *p : pinned)
         if (p) (void)hipHostFree(p);
     for (auto &e : ctx->ev)
@@ -343,8 +352,9 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->blk_exit, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_count, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (n_blocks + 1) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint16_t) << et::DEC_LUT_BITS_MAX));
+    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint32_t) << et::DEC_LUT_BITS_MAX));
     ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->subt, SUB_TABLE_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
     return ET_OK;
 }
@@ -499,12 +509,21 @@ extern "C" int et_encode(et_ctx *ctx, const uint8_t *text, size_t n, uint8_t *ou
 // ---------------------------------------------------------------------------------
 namespace {
 
-// First-level table indexed by the next lut_bits bits; codes longer than that go to
-// a short list searched linearly (they are the rare symbols by construction).
-void build_decode_tables(const et_codebook *cb, uint16_t *lut, uint32_t *longc, uint32_t *lut_bits, uint32_t *n_long) {
-    const uint32_t k = cb->max_length < et::DEC_LUT_BITS_MAX ? (cb->max_length ? cb->max_length : 1) : et::DEC_LUT_BITS_MAX;
-    std::memset(lut, 0, sizeof(uint16_t) << k);
-    uint32_t nl = 0;
+// First-level table indexed by the next lut_bits bits: the symbol whose code is a
+// prefix of the index and, when a second whole code also fits in the remaining bits,
+// that one too (layout: et_kernels.h LUT_*).  Codes longer than lut_bits go to a short
+// list searched linearly (they are the rare symbols by construction).
+struct HostDecodeTables {
+    uint32_t lut_bits, n_long, sub_bits, n_sub;
+};
+
+void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t *lut, uint32_t *longc, uint16_t *sub, HostDecodeTables *out) {
+    const uint32_t k = cb->max_length < lut_bits_max ? (cb->max_length ? cb->max_length : 1) : lut_bits_max;
+    const uint32_t n = 1u << k;
+    const uint32_t sub_bits = cb->max_length > k ? (cb->max_length - k < et::DEC_SUB_BITS_MAX ? cb->max_length - k : et::DEC_SUB_BITS_MAX) : 0;
+    std::vector<uint16_t> single(n, 0);  // (len << 8) | sym of the code that prefixes the index
+    std::vector<int> sub_of(n, -1);      // second-level table of a first-level index
+    uint32_t nl = 0, n_sub = 0;
     for (int s = 0; s < 256; ++s) {
         const uint32_t len = cb->length[s];
         if (!len) continue;
@@ -512,15 +531,43 @@ void build_decode_tables(const et_codebook *cb, uint16_t *lut, uint32_t *longc, 
         const uint32_t meta = (len << 8) | static_cast<uint32_t>(s);
         if (len <= k) {
             const uint32_t first = code << (k - len), span = 1u << (k - len);
-            for (uint32_t i = 0; i < span; ++i) lut[first + i] = static_cast<uint16_t>(meta);
+            for (uint32_t i = 0; i < span; ++i) single[first + i] = static_cast<uint16_t>(meta);
         } else {
             longc[2 * nl] = code << (32 - len);
             longc[2 * nl + 1] = meta;
             ++nl;
+            const uint32_t prefix = code >> (len - k), rest_bits = len - k;
+            if (sub_of[prefix] < 0 && n_sub < et::DEC_SUB_TABLES_MAX) {
+                sub_of[prefix] = static_cast<int>(n_sub);
+                std::memset(sub + (static_cast<size_t>(n_sub) << sub_bits), 0, sizeof(uint16_t) << sub_bits);
+                ++n_sub;
+            }
+            if (sub_of[prefix] >= 0 && rest_bits <= sub_bits) {
+                const uint32_t rest = code & ((1u << rest_bits) - 1u);
+                uint16_t *t = sub + (static_cast<size_t>(sub_of[prefix]) << sub_bits);
+                const uint32_t first = rest << (sub_bits - rest_bits), span = 1u << (sub_bits - rest_bits);
+                for (uint32_t i = 0; i < span; ++i) t[first + i] = static_cast<uint16_t>(meta);
+            }
         }
     }
-    *lut_bits = k;
-    *n_long = nl;
+    for (uint32_t v = 0; v < n; ++v) {
+        const uint32_t e1 = single[v], len1 = e1 >> 8;
+        uint32_t entry = 0;
+        if (len1) {
+            entry = (e1 & 0xffu) | (len1 << et::LUT_LEN1_SHIFT);
+            const uint32_t rest = (v << len1) & (n - 1);  // the following k - len1 bits, left-aligned in k
+            const uint32_t e2 = single[rest], len2 = e2 >> 8;
+            if (len2 && len1 + len2 <= k)
+                entry |= ((e2 & 0xffu) << 8) | ((len1 + len2) << et::LUT_LEN2_SHIFT) | (1u << et::LUT_TWO_SHIFT);
+        } else if (sub_of[v] >= 0) {
+            entry = static_cast<uint32_t>(sub_of[v]) | (1u << et::LUT_SUB_SHIFT);
+        }
+        lut[v] = entry;
+    }
+    out->lut_bits = k;
+    out->n_long = nl;
+    out->sub_bits = sub_bits;
+    out->n_sub = n_sub;
 }
 
 }  // namespace
@@ -549,21 +596,24 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint16_t) << et::DEC_LUT_BITS_MAX));
+    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint32_t) << et::DEC_LUT_BITS_MAX));
     ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->subt, SUB_TABLE_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
 
     const double t0 = now_ms();
     ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
-    uint32_t lut_bits = 0, n_long = 0;
-    build_decode_tables(cb, ctx->h_lut, ctx->h_long, &lut_bits, &n_long);
+    HostDecodeTables ht;
+    build_decode_tables(cb, ctx->lut_bits_max, ctx->h_lut, ctx->h_long, ctx->h_sub, &ht);
+    const uint32_t lut_bits = ht.lut_bits, n_long = ht.n_long;
     const double t1 = now_ms();
     record(ctx, 0);
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, sizeof(uint16_t) << lut_bits, hipMemcpyHostToDevice, ctx->stream));
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, sizeof(uint32_t) << lut_bits, hipMemcpyHostToDevice, ctx->stream));
     if (n_long) ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, n_long * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (ht.n_sub) ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, (static_cast<size_t>(ht.n_sub) << ht.sub_bits) * sizeof(uint16_t) + 16, hipMemcpyHostToDevice, ctx->stream));
+    const et::DecodeTables tb{static_cast<const uint32_t *>(ctx->lut.p), static_cast<const uint32_t *>(ctx->longc.p),
+                              static_cast<const uint16_t *>(ctx->subt.p), lut_bits, n_long, ht.sub_bits, ht.n_sub};
 
-    const uint16_t *lut = static_cast<const uint16_t *>(ctx->lut.p);
-    const uint32_t *longc = static_cast<const uint32_t *>(ctx->longc.p);
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
     uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
     uint32_t *blk_count = static_cast<uint32_t *>(ctx->blk_count.p);
@@ -572,12 +622,12 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
 
     // D1: sweep 0 guesses, later sweeps repair; stop after a sweep that changed nothing.
     uint32_t iters = 0;
-    et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, lut, longc, lut_bits, n_long, 0, sub_state, blk_exit, blk_count, flag);
+    et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, sub_state, blk_exit, blk_count, flag);
     ET_HIP(hipGetLastError());
     ++iters;
     for (;;) {
         ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, lut, longc, lut_bits, n_long, iters, sub_state, blk_exit, blk_count, flag);
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, sub_state, blk_exit, blk_count, flag);
         ET_HIP(hipGetLastError());
         ++iters;
         ET_HIP(hipMemcpyAsync(ctx->h_scalar, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -599,7 +649,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
 
     // D3
     if (n_out) {
-        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, lut, longc, lut_bits, n_long, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out));
+        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out));
         ET_HIP(hipGetLastError());
     }
     record(ctx, 3);

@@ -13,8 +13,31 @@ constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-st
 
 constexpr uint32_t SUB_BITS = 256;                             // decode: bits per lane subsequence
 constexpr uint32_t DEC_BLOCK_WORDS = BLOCK * SUB_BITS / 32;    // 8 KiB of bitstream per workgroup
-constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: 4096 x u16 in LDS
+constexpr uint32_t DEC_GUARD_WORDS = 4;                        // words a lane may read past its workgroup's 8 KiB
+constexpr uint32_t DEC_SDATA_WORDS = ((DEC_BLOCK_WORDS + DEC_GUARD_WORDS) + ((DEC_BLOCK_WORDS + DEC_GUARD_WORDS) >> 5) + 4) & ~3u;  // 1 pad word per 32
+constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: at most 4096 x u32 in LDS
+constexpr uint32_t DEC_LUT_BITS_DEFAULT = 11;                  // measured best on text (K = 10..11 tie, 12 and 9 slower)
+// first-level table entry: byte 0 = first symbol, byte 1 = second symbol,
+// bits 16..19 = length of the first code (0: longer than the table or no code),
+// bits 20..23 = length of both codes, bit 24 = entry holds two symbols
+constexpr uint32_t LUT_LEN1_SHIFT = 16, LUT_LEN2_SHIFT = 20, LUT_TWO_SHIFT = 24;
+// escape entries (first length 0): bit 25 set -> byte 0 is the index of a second-level
+// table of 1 << sub_bits u16 entries ((len << 8) | sym, 0 = not here) indexed by the
+// sub_bits bits that follow the first lut_bits
+constexpr uint32_t LUT_SUB_SHIFT = 25;
+constexpr uint32_t DEC_SUB_BITS_MAX = 8, DEC_SUB_TABLES_MAX = 16;
 constexpr uint32_t DEC_STAGE_BYTES = 16384;                    // LDS staging of decoded symbols
+
+// Device-resident decode tables (built on the host, et_api.cpp build_decode_tables).
+struct DecodeTables {
+    const uint32_t *lut;     // [1 << lut_bits] first-level entries (LUT_* above)
+    const uint32_t *longc;   // [n_long * 2]: {left-aligned code, (len << 8) | sym} of every code longer than lut_bits
+    const uint16_t *sub;     // [n_sub << sub_bits] second-level tables
+    uint32_t lut_bits;
+    uint32_t n_long;
+    uint32_t sub_bits;
+    uint32_t n_sub;
+};
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist);
@@ -24,11 +47,11 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32);
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
-                     const uint16_t *lut, const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, uint32_t iter,
+                     const DecodeTables &tb, uint32_t iter,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed);
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *blk_off);
-void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const uint16_t *lut,
-                      const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, const uint32_t *sub_state,
+void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
+                      const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out);
 
 }  // namespace et

@@ -440,12 +440,40 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles_long(const uint8_t *__re
 // exit[i] to a fixed point; Huffman codes self-synchronise, so a wrong guess heals
 // within a few codewords and the fixed point is reached after two or three sweeps.
 // The unique fixed point with start[0] = the true first bit is the true parse.
-struct DecodeTables {
-    const uint16_t *lut;     // [1 << lut_bits]: (len << 8) | sym, len == 0 -> long/invalid
-    const uint32_t *longc;   // [n_long * 2]: {left-aligned code, (len << 8) | sym}
-    uint32_t lut_bits;
-    uint32_t n_long;
+//
+// Inner loop (walk_subsequence): each lane keeps the next 32..64 stream bits in a
+// 64-bit register and refills it with ONE LDS word per 32 bits consumed; a lookup of
+// the next lut_bits bits in an LDS table yields up to TWO symbols per step.  The
+// staged bitstream is padded by one word per 32 so that lanes, which read at a stride
+// of SUB_BITS / 32 = 8 words, fall on different LDS banks.
+__device__ __forceinline__ uint32_t phys(uint32_t logical_word) { return logical_word + (logical_word >> 5); }
+
+// Dynamic LDS carve (all offsets multiples of 16 bytes).
+struct DecodeSmem {
+    uint32_t *sdata;   // DEC_SDATA_WORDS
+    uint32_t *lut;     // 1 << lut_bits
+    uint32_t *longc;   // 512
+    uint16_t *sub;     // n_sub << sub_bits
+    uint32_t *exits;   // BLOCK
+    uint32_t *scratch; // 8 (scan scratch [0..3], flag [4])
+    uint8_t *stage;    // DEC_STAGE_BYTES (write kernel only)
 };
+
+extern __shared__ __attribute__((aligned(16))) uint8_t dec_smem_raw[];
+
+__device__ __forceinline__ uint32_t sub_words(const DecodeTables &tb) { return (((tb.n_sub << tb.sub_bits) + 7u) & ~7u) / 2; }
+
+__device__ __forceinline__ DecodeSmem carve_decode_smem(const DecodeTables &tb) {
+    DecodeSmem m;
+    m.sdata = reinterpret_cast<uint32_t *>(dec_smem_raw);
+    m.lut = m.sdata + DEC_SDATA_WORDS;
+    m.longc = m.lut + (1u << tb.lut_bits);
+    m.sub = reinterpret_cast<uint16_t *>(m.longc + 512);
+    m.exits = m.longc + 512 + sub_words(tb);
+    m.scratch = m.exits + BLOCK;
+    m.stage = reinterpret_cast<uint8_t *>(m.scratch + 8);
+    return m;
+}
 
 __device__ __forceinline__ uint32_t load_be32_guarded(const uint32_t *__restrict__ words, uint64_t idx, uint64_t n_bytes) {
     // big-endian numeric value of stream bytes [4*idx, 4*idx+4), zero beyond n_bytes
@@ -458,32 +486,17 @@ __device__ __forceinline__ uint32_t load_be32_guarded(const uint32_t *__restrict
     return v;
 }
 
-// Stage the workgroup's SUBS_PER_BLOCK subsequences (+2 guard words) into LDS as
-// host-order words whose numeric MSB is the first stream bit.
-__device__ __forceinline__ void stage_block_words(uint32_t *sdata, const uint32_t *__restrict__ words, uint64_t first_word,
-                                                  uint64_t n_bytes) {
-    for (uint32_t i = threadIdx.x; i < DEC_BLOCK_WORDS + 2; i += BLOCK) sdata[i] = load_be32_guarded(words, first_word + i, n_bytes);
-}
-
-__device__ __forceinline__ uint32_t peek32(const uint32_t *sdata, uint32_t rel_bit) {
-    const uint32_t k = rel_bit >> 5, sh = rel_bit & 31;
-    return __funnelshift_l(sdata[k + 1], sdata[k], sh);
-}
-
-// Length and symbol of the codeword at the top of `window`; len == 0 -> no code matches.
-__device__ __forceinline__ uint32_t match_code(const uint16_t *s_lut, const uint32_t *s_long, uint32_t lut_bits, uint32_t n_long,
-                                               uint32_t window) {
-    uint32_t e = s_lut[window >> (32 - lut_bits)];
-    if ((e >> 8) == 0 && n_long) {
-        for (uint32_t i = 0; i < n_long; ++i) {
-            const uint32_t meta = s_long[2 * i + 1], len = meta >> 8;
-            if (((window ^ s_long[2 * i]) >> (32 - len)) == 0) {
-                e = meta;
-                break;
-            }
-        }
-    }
-    return e;
+// Stage the workgroup's 8 KiB of bitstream (+ guard words) into LDS as host-order
+// words whose numeric MSB is the first stream bit, and the lookup tables next to it.
+__device__ __forceinline__ void stage_block(const DecodeSmem &m, const DecodeTables &tb, const uint32_t *__restrict__ words,
+                                            uint64_t first_word, uint64_t n_bytes) {
+    for (uint32_t i = threadIdx.x; i < DEC_BLOCK_WORDS + DEC_GUARD_WORDS; i += BLOCK)
+        m.sdata[phys(i)] = load_be32_guarded(words, first_word + i, n_bytes);
+    const uint32_t n_lut = 1u << tb.lut_bits;
+    for (uint32_t i = threadIdx.x; i < n_lut; i += BLOCK) m.lut[i] = tb.lut[i];
+    for (uint32_t i = threadIdx.x; i < tb.n_long * 2; i += BLOCK) m.longc[i] = tb.longc[i];
+    const uint32_t n_sub_words = sub_words(tb);
+    for (uint32_t i = threadIdx.x; i < n_sub_words; i += BLOCK) reinterpret_cast<uint32_t *>(m.sub)[i] = reinterpret_cast<const uint32_t *>(tb.sub)[i];
 }
 
 struct SubResult {
@@ -491,33 +504,85 @@ struct SubResult {
     uint32_t count;
 };
 
-// Walk the codewords that begin inside subsequence `sub` of the workgroup's staged
-// data, from `start_rel`.  `limit_rel` = stream end relative to the block's first bit.
-template <bool WRITE>
-__device__ __forceinline__ SubResult walk_subsequence(const uint32_t *sdata, const uint16_t *s_lut, const uint32_t *s_long,
-                                                      uint32_t lut_bits, uint32_t n_long, uint32_t sub, uint32_t start_rel,
-                                                      uint64_t limit_rel, uint8_t *stage, uint32_t stage_pos, uint32_t stage_lo,
+// Walk the codewords that begin inside subsequence `sub` of the staged block, from
+// bit `start_rel` of it.  `lim` = stream end in bits from the block's first bit
+// (clamped to u32).  A symbol belongs to the subsequence in which it BEGINS.
+// WRITE: 0 = count only, 1 = store every symbol at stage[stage_pos + index] (the
+// caller guarantees the whole range is inside the stage), 2 = store only indices in
+// [stage_lo, stage_hi).
+template <int WRITE>
+__device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const DecodeTables &tb, uint32_t sub,
+                                                      uint32_t start_rel, uint32_t lim, uint32_t stage_pos, uint32_t stage_lo,
                                                       uint32_t stage_hi) {
+    const uint32_t lut_bits = tb.lut_bits;
     uint32_t pos = sub * SUB_BITS + start_rel;
     const uint32_t end = (sub + 1) * SUB_BITS;
     uint32_t count = 0;
+    const uint32_t k0 = pos >> 5, sh = pos & 31;
+    unsigned long long buf = ((static_cast<unsigned long long>(m.sdata[phys(k0)]) << 32) | m.sdata[phys(k0 + 1)]) << sh;
+    uint32_t avail = 64 - sh;  // invariant at the loop head: avail >= 32, bits below `avail` are 0
+    uint32_t next_word = k0 + 2;
+    const uint32_t top = 64 - lut_bits;
     while (pos < end) {
-        const uint32_t e = match_code(s_lut, s_long, lut_bits, n_long, peek32(sdata, pos));
-        uint32_t len = e >> 8;
-        const bool valid = len != 0;
-        if (!valid) len = 1;  // not a codeword (only on a wrong guess or a malformed stream): resynchronise bit by bit
-        if (static_cast<uint64_t>(pos) + len > limit_rel) {
-            pos = end;  // ran off the stream: nothing further begins here
-            break;
+        const uint32_t e = m.lut[static_cast<uint32_t>(buf >> top)];
+        const uint32_t len1 = (e >> LUT_LEN1_SHIFT) & 15u;
+        uint32_t syms = e;  // byte 0 = first symbol, byte 1 = second
+        // the pair is usable only if the second symbol also begins before `end`
+        bool two = ((e >> LUT_TWO_SHIFT) & 1u) && pos + lut_bits <= end;
+        uint32_t len = two ? ((e >> LUT_LEN2_SHIFT) & 15u) : len1;
+        bool valid = true;
+        if (len1 == 0) {  // longer than lut_bits, or no codeword at all
+            const uint32_t window = static_cast<uint32_t>(buf >> 32);
+            valid = false;
+            two = false;
+            len = 1;  // not a codeword (only on a wrong guess or a malformed stream): resynchronise bit by bit
+            uint32_t hit = 0;
+            if ((e >> LUT_SUB_SHIFT) & 1u)
+                hit = m.sub[((e & 0xffu) << tb.sub_bits) | ((window << lut_bits) >> (32 - tb.sub_bits))];
+            if (hit == 0) {  // deeper than both tables (or no table slot left): search the list
+                for (uint32_t i = 0; i < tb.n_long; ++i) {
+                    const uint32_t meta = m.longc[2 * i + 1], l = meta >> 8;
+                    if (((window ^ m.longc[2 * i]) >> (32 - l)) == 0) {
+                        hit = meta;
+                        break;
+                    }
+                }
+            }
+            if (hit) {
+                len = hit >> 8;
+                syms = hit & 0xffu;
+                valid = true;
+            }
+        }
+        if (pos + len > lim) {  // only ever true in the stream's last subsequences
+            if (two && pos + len1 <= lim) {
+                two = false;
+                len = len1;
+            } else {
+                pos = end;  // ran off the stream: nothing further begins here
+                break;
+            }
         }
         if (valid) {
-            if (WRITE) {
+            if (WRITE == 1) {
                 const uint32_t o = stage_pos + count;
-                if (o >= stage_lo && o < stage_hi) stage[o - stage_lo] = static_cast<uint8_t>(e & 0xffu);
+                m.stage[o] = static_cast<uint8_t>(syms);
+                if (two) m.stage[o + 1] = static_cast<uint8_t>(syms >> 8);
+            } else if (WRITE == 2) {
+                const uint32_t o = stage_pos + count;
+                if (o >= stage_lo && o < stage_hi) m.stage[o - stage_lo] = static_cast<uint8_t>(syms);
+                if (two && o + 1 >= stage_lo && o + 1 < stage_hi) m.stage[o + 1 - stage_lo] = static_cast<uint8_t>(syms >> 8);
             }
-            ++count;
+            count += two ? 2u : 1u;
         }
         pos += len;
+        buf <<= len;
+        avail -= len;
+        if (avail < 32) {
+            buf |= static_cast<unsigned long long>(m.sdata[phys(next_word)]) << (32 - avail);
+            avail += 32;
+            ++next_word;
+        }
     }
     SubResult r;
     r.exit_rel = pos - end;
@@ -525,10 +590,9 @@ __device__ __forceinline__ SubResult walk_subsequence(const uint32_t *sdata, con
     return r;
 }
 
-__device__ __forceinline__ void load_decode_tables(const DecodeTables &tb, uint16_t *s_lut, uint32_t *s_long) {
-    const uint32_t n_lut = 1u << tb.lut_bits;
-    for (uint32_t i = threadIdx.x; i < n_lut; i += BLOCK) s_lut[i] = tb.lut[i];
-    for (uint32_t i = threadIdx.x; i < tb.n_long * 2; i += BLOCK) s_long[i] = tb.longc[i];
+__device__ __forceinline__ uint32_t block_limit(uint64_t n_bytes, uint64_t block) {
+    const uint64_t rel = n_bytes * 8 - block * DEC_BLOCK_WORDS * 32;
+    return rel > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(rel);
 }
 
 // D1.  iter == 0: every subsequence guesses that a codeword begins at its first bit
@@ -542,12 +606,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
                                                     uint64_t n_subs, DecodeTables tb, uint32_t iter,
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
                                                     uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed) {
-    __shared__ uint32_t sdata[DEC_BLOCK_WORDS + 2];
-    __shared__ uint16_t s_lut[1 << DEC_LUT_BITS_MAX];
-    __shared__ uint32_t s_long[512];
-    __shared__ uint32_t s_exit[BLOCK];
-    __shared__ uint32_t s_flag;
-    __shared__ uint32_t scratch[4];
+    const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
     const uint64_t b = blockIdx.x;
     const uint64_t sub_g = b * BLOCK + tid;
@@ -568,28 +627,27 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
             const uint32_t in = (b == 0) ? first_bit : blk_exit[b - 1];
             need = in != start;
             start = in;
-            s_flag = need;
+            m.scratch[4] = need;
         }
         __syncthreads();
-        if (!s_flag) return;
+        if (!m.scratch[4]) return;
         if (tid == 0) *changed = 1;
     }
-    stage_block_words(sdata, words, b * DEC_BLOCK_WORDS, n_bytes);
-    load_decode_tables(tb, s_lut, s_long);
+    stage_block(m, tb, words, b * DEC_BLOCK_WORDS, n_bytes);
     __syncthreads();
 
-    const uint64_t limit_rel = n_bytes * 8 - b * DEC_BLOCK_WORDS * 32;
+    const uint32_t lim = block_limit(n_bytes, b);
     for (;;) {
         if (need) {
-            const SubResult r = walk_subsequence<false>(sdata, s_lut, s_long, tb.lut_bits, tb.n_long, tid, start, limit_rel, nullptr, 0, 0, 0);
+            const SubResult r = walk_subsequence<0>(m, tb, tid, start, lim, 0, 0, 0);
             exit_rel = r.exit_rel;
             count = r.count;
         }
-        s_exit[tid] = exit_rel;
+        m.exits[tid] = exit_rel;
         __syncthreads();
         need = false;
         if (tid > 0 && live) {
-            const uint32_t in = s_exit[tid - 1];
+            const uint32_t in = m.exits[tid - 1];
             need = in != start;
             start = in;
         }
@@ -597,7 +655,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
     }
     if (live) sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
     uint32_t total;
-    block_exclusive_scan(live ? count : 0u, scratch, &total);
+    block_exclusive_scan(live ? count : 0u, m.scratch, &total);
     if (tid == 0) blk_count[b] = total;
     // exit of the last live subsequence of this workgroup
     const uint64_t last_live = (n_subs - b * BLOCK >= BLOCK) ? BLOCK - 1 : (n_subs - b * BLOCK - 1);
@@ -635,11 +693,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
                                                      DecodeTables tb, const uint32_t *__restrict__ sub_state,
                                                      const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
                                                      uint8_t *__restrict__ out) {
-    __shared__ uint32_t sdata[DEC_BLOCK_WORDS + 2];
-    __shared__ uint16_t s_lut[1 << DEC_LUT_BITS_MAX];
-    __shared__ uint32_t s_long[512];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[DEC_STAGE_BYTES];
-    __shared__ uint32_t scratch[4];
+    const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
     const uint64_t b = blockIdx.x;
     const uint64_t o0 = blk_off[b];
@@ -649,32 +703,35 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
     const uint32_t st = live ? sub_state[sub_g] : 0u;
     const uint32_t start = st & 0xffu, count = live ? (st >> 16) : 0u;
 
-    stage_block_words(sdata, words, b * DEC_BLOCK_WORDS, n_bytes);
-    load_decode_tables(tb, s_lut, s_long);
+    stage_block(m, tb, words, b * DEC_BLOCK_WORDS, n_bytes);
     uint32_t block_total;
-    const uint32_t my_off = block_exclusive_scan(count, scratch, &block_total);  // barrier inside covers the staging
-    __syncthreads();
+    const uint32_t my_off = block_exclusive_scan(count, m.scratch, &block_total);  // its barrier also covers the staging
 
     uint64_t o1 = o0 + block_total;
     if (o1 > n_symbols) o1 = n_symbols;
     const uint32_t n_out = static_cast<uint32_t>(o1 - o0);
     const uint32_t phase = static_cast<uint32_t>(o0 & 15);  // stage offset of the first symbol
-    const uint64_t limit_rel = n_bytes * 8 - b * DEC_BLOCK_WORDS * 32;
+    const uint32_t lim = block_limit(n_bytes, b);
     uint8_t *out_base = out + (o0 - phase);
 
-    // stage positions are `phase + symbol index`; windows of DEC_STAGE_BYTES of them
+    // stage positions are `phase + symbol index`; windows of DEC_STAGE_BYTES of them.
+    // Usual case: the workgroup's symbols fit one window and none is clamped away.
+    const bool one_window = phase + block_total <= DEC_STAGE_BYTES && n_out == block_total;
     for (uint32_t win = 0; win < phase + n_out; win += DEC_STAGE_BYTES) {
         const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
         const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
-        if (live && my_lo < win_hi && my_hi > win)
-            walk_subsequence<true>(sdata, s_lut, s_long, tb.lut_bits, tb.n_long, tid, start, limit_rel, stage, my_lo, win, win_hi);
+        if (one_window) {
+            if (live && count) walk_subsequence<1>(m, tb, tid, start, lim, my_lo, 0, 0);
+        } else if (live && my_lo < win_hi && my_hi > win) {
+            walk_subsequence<2>(m, tb, tid, start, lim, my_lo, win, win_hi);
+        }
         __syncthreads();
         const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
         for (uint32_t g = win + tid * 16; g < win_hi; g += BLOCK * 16) {
             if (g >= lo_valid && g + 16 <= win_hi) {
-                *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(stage + (g - win));
+                *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(m.stage + (g - win));
             } else {
-                for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = stage[k - win];
+                for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = m.stage[k - win];
             }
         }
         __syncthreads();
@@ -684,6 +741,11 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
 // --------------------------------------------------------------------------------
 // launch wrappers (plain C++ callable; everything is enqueued on `stream`)
 // --------------------------------------------------------------------------------
+static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage) {
+    const uint32_t sub_w = (((tb.n_sub << tb.sub_bits) + 7u) & ~7u) / 2;
+    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + 512 + sub_w + BLOCK + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES : 0);
+}
+
 static inline uint32_t hist_grid(uint32_t n_tiles) { return n_tiles < MAX_GRID ? n_tiles : MAX_GRID; }
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
@@ -717,23 +779,21 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
 }
 
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
-                     const uint16_t *lut, const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, uint32_t iter,
+                     const DecodeTables &tb, uint32_t iter,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
-    DecodeTables tb{lut, longc, lut_bits, n_long};
-    hipLaunchKernelGGL(k_dec_sync, dim3(n_blocks), dim3(BLOCK), 0, stream, words, n_bytes, first_bit, n_subs, tb, iter, sub_state, blk_exit, blk_count, changed);
+    hipLaunchKernelGGL(k_dec_sync, dim3(n_blocks), dim3(BLOCK), decode_smem_bytes(tb, false), stream, words, n_bytes, first_bit, n_subs, tb, iter, sub_state, blk_exit, blk_count, changed);
 }
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *blk_off) {
     hipLaunchKernelGGL(k_dec_scan, dim3(1), dim3(1024), 0, stream, blk_count, n_blocks, blk_off);
 }
 
-void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const uint16_t *lut,
-                      const uint32_t *longc, uint32_t lut_bits, uint32_t n_long, const uint32_t *sub_state,
+void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
+                      const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
-    DecodeTables tb{lut, longc, lut_bits, n_long};
-    hipLaunchKernelGGL(k_dec_write, dim3(n_blocks), dim3(BLOCK), 0, stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_symbols, out);
+    hipLaunchKernelGGL(k_dec_write, dim3(n_blocks), dim3(BLOCK), decode_smem_bytes(tb, true), stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_symbols, out);
 }
 
 }  // namespace et
