@@ -14,7 +14,10 @@ constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-st
 constexpr uint32_t SUB_BITS = 256;                             // decode: bits per lane subsequence
 constexpr uint32_t DEC_BLOCK_WORDS = BLOCK * SUB_BITS / 32;    // 8 KiB of bitstream per workgroup
 constexpr uint32_t DEC_GUARD_WORDS = 4;                        // words a lane may read past its workgroup's 8 KiB
-constexpr uint32_t DEC_SDATA_WORDS = ((DEC_BLOCK_WORDS + DEC_GUARD_WORDS) + ((DEC_BLOCK_WORDS + DEC_GUARD_WORDS) >> 5) + 4) & ~3u;  // 1 pad word per 32
+constexpr uint32_t DEC_FRONT_WORDS = 4;                        // words staged BEFORE the workgroup's 8 KiB (warm-up run-in)
+constexpr uint32_t DEC_WARMUP_BITS = DEC_FRONT_WORDS * 32;     // run-in before each subsequence in the first sync sweep
+constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GUARD_WORDS;
+constexpr uint32_t DEC_SDATA_WORDS = (DEC_STAGED_WORDS + (DEC_STAGED_WORDS >> 5) + 4) & ~3u;  // 1 pad word per 32
 constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: at most 4096 x u32 in LDS
 constexpr uint32_t DEC_LUT_BITS_DEFAULT = 11;                  // measured best on text (K = 10..11 tie, 12 and 9 slower)
 // first-level table entry: byte 0 = first symbol, byte 1 = second symbol,

@@ -452,7 +452,6 @@ __device__ __forceinline__ uint32_t phys(uint32_t logical_word) { return logical
 struct DecodeSmem {
     uint32_t *sdata;   // DEC_SDATA_WORDS
     uint32_t *lut;     // 1 << lut_bits
-    uint32_t *longc;   // 512
     uint16_t *sub;     // n_sub << sub_bits
     uint32_t *exits;   // BLOCK
     uint32_t *scratch; // 8 (scan scratch [0..3], flag [4])
@@ -467,9 +466,8 @@ __device__ __forceinline__ DecodeSmem carve_decode_smem(const DecodeTables &tb) 
     DecodeSmem m;
     m.sdata = reinterpret_cast<uint32_t *>(dec_smem_raw);
     m.lut = m.sdata + DEC_SDATA_WORDS;
-    m.longc = m.lut + (1u << tb.lut_bits);
-    m.sub = reinterpret_cast<uint16_t *>(m.longc + 512);
-    m.exits = m.longc + 512 + sub_words(tb);
+    m.sub = reinterpret_cast<uint16_t *>(m.lut + (1u << tb.lut_bits));
+    m.exits = m.lut + (1u << tb.lut_bits) + sub_words(tb);
     m.scratch = m.exits + BLOCK;
     m.stage = reinterpret_cast<uint8_t *>(m.scratch + 8);
     return m;
@@ -490,108 +488,159 @@ __device__ __forceinline__ uint32_t load_be32_guarded(const uint32_t *__restrict
 // words whose numeric MSB is the first stream bit, and the lookup tables next to it.
 __device__ __forceinline__ void stage_block(const DecodeSmem &m, const DecodeTables &tb, const uint32_t *__restrict__ words,
                                             uint64_t first_word, uint64_t n_bytes) {
-    for (uint32_t i = threadIdx.x; i < DEC_BLOCK_WORDS + DEC_GUARD_WORDS; i += BLOCK)
-        m.sdata[phys(i)] = load_be32_guarded(words, first_word + i, n_bytes);
+    // logical word i of the stage = stream word first_word - DEC_FRONT_WORDS + i (zero before the stream)
+    for (uint32_t i = threadIdx.x; i < DEC_STAGED_WORDS; i += BLOCK) {
+        const bool before = first_word + i < DEC_FRONT_WORDS;
+        m.sdata[phys(i)] = before ? 0u : load_be32_guarded(words, first_word + i - DEC_FRONT_WORDS, n_bytes);
+    }
     const uint32_t n_lut = 1u << tb.lut_bits;
     for (uint32_t i = threadIdx.x; i < n_lut; i += BLOCK) m.lut[i] = tb.lut[i];
-    for (uint32_t i = threadIdx.x; i < tb.n_long * 2; i += BLOCK) m.longc[i] = tb.longc[i];
     const uint32_t n_sub_words = sub_words(tb);
     for (uint32_t i = threadIdx.x; i < n_sub_words; i += BLOCK) reinterpret_cast<uint32_t *>(m.sub)[i] = reinterpret_cast<const uint32_t *>(tb.sub)[i];
 }
 
 struct SubResult {
+    uint32_t start_rel;
     uint32_t exit_rel;
     uint32_t count;
 };
 
-// Walk the codewords that begin inside subsequence `sub` of the staged block, from
-// bit `start_rel` of it.  `lim` = stream end in bits from the block's first bit
-// (clamped to u32).  A symbol belongs to the subsequence in which it BEGINS.
+// One table step: the codeword(s) at the top of `window`.  Returns the bits consumed;
+// n = symbols decoded (0: no codeword there), syms = first symbol in byte 0, second
+// in byte 1 when two.  Only the escape for codes longer than the first-level table
+// (~0.1 % of symbols) branches.
+__device__ __forceinline__ uint32_t table_step(const DecodeSmem &m, const DecodeTables &tb, uint32_t window, bool allow_pair,
+                                               uint32_t &syms, uint32_t &n, bool &two, uint32_t &len1) {
+    const uint32_t e = m.lut[window >> (32 - tb.lut_bits)];
+    len1 = (e >> LUT_LEN1_SHIFT) & 15u;
+    syms = e;
+    two = ((e >> LUT_TWO_SHIFT) & 1u) && allow_pair;
+    uint32_t len = two ? ((e >> LUT_LEN2_SHIFT) & 15u) : len1;
+    n = two ? 2u : 1u;
+    if (len1 == 0) {  // longer than lut_bits, or no codeword at all
+        two = false;
+        uint32_t hit = 0;
+        if ((e >> LUT_SUB_SHIFT) & 1u)
+            hit = m.sub[((e & 0xffu) << tb.sub_bits) | ((window << tb.lut_bits) >> (32 - tb.sub_bits))];
+        if (hit == 0) {  // deeper than both tables (or no table slot left): search the list in global memory
+            for (uint32_t i = 0; i < tb.n_long; ++i) {
+                const uint32_t meta = tb.longc[2 * i + 1], l = meta >> 8;
+                if (((window ^ tb.longc[2 * i]) >> (32 - l)) == 0) {
+                    hit = meta;
+                    break;
+                }
+            }
+        }
+        // no hit: not a codeword (only on a wrong guess or a malformed stream): resynchronise bit by bit
+        len = hit ? (hit >> 8) : 1u;
+        syms = hit & 0xffu;
+        n = hit ? 1u : 0u;
+    }
+    return len;
+}
+
+// Walk the codewords that begin inside subsequence `sub` of the staged block.
+// Positions are bits from the first STAGED bit (DEC_WARMUP_BITS before the block).
+//   WARM: start DEC_WARMUP_BITS before the subsequence and run in (single symbols,
+//         nothing counted); the first codeword boundary at or after the subsequence's
+//         first bit becomes start_rel.  Otherwise start at the given start_rel.
+//   `lim` = stream end (same origin, clamped to u32), tested only when CHECK_LIM (the
+//         stream's last workgroup).
+// A symbol belongs to the subsequence in which it BEGINS.
+//
+// The loop bodies are written without divergent branches (one scalar unit serves the
+// four SIMDs of a CU, and exec-mask bookkeeping was the first bottleneck): the stream
+// window is the 64-bit pair {r0, r1} read at bit `sh` in [1, 32] with one
+// v_alignbit_b32, r2 holds the word after it, and register rotation, pair selection
+// and the second-symbol store are selects.
+//
 // WRITE: 0 = count only, 1 = store every symbol at stage[stage_pos + index] (the
 // caller guarantees the whole range is inside the stage), 2 = store only indices in
 // [stage_lo, stage_hi).
-template <int WRITE>
+template <int WRITE, bool CHECK_LIM, bool WARM>
 __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const DecodeTables &tb, uint32_t sub,
                                                       uint32_t start_rel, uint32_t lim, uint32_t stage_pos, uint32_t stage_lo,
                                                       uint32_t stage_hi) {
-    const uint32_t lut_bits = tb.lut_bits;
-    uint32_t pos = sub * SUB_BITS + start_rel;
-    const uint32_t end = (sub + 1) * SUB_BITS;
+    const uint32_t begin = DEC_WARMUP_BITS + sub * SUB_BITS;
+    const uint32_t end = begin + SUB_BITS;
+    const uint32_t end_two = end - tb.lut_bits;  // a pair is usable iff its window starts at or before this bit
+    const uint32_t dummy = DEC_STAGE_BYTES + 16 + threadIdx.x * 4;  // where the second byte of a non-pair goes
+    uint32_t pos = WARM ? begin - DEC_WARMUP_BITS : begin + start_rel;
     uint32_t count = 0;
-    const uint32_t k0 = pos >> 5, sh = pos & 31;
-    unsigned long long buf = ((static_cast<unsigned long long>(m.sdata[phys(k0)]) << 32) | m.sdata[phys(k0 + 1)]) << sh;
-    uint32_t avail = 64 - sh;  // invariant at the loop head: avail >= 32, bits below `avail` are 0
-    uint32_t next_word = k0 + 2;
-    const uint32_t top = 64 - lut_bits;
-    while (pos < end) {
-        const uint32_t e = m.lut[static_cast<uint32_t>(buf >> top)];
-        const uint32_t len1 = (e >> LUT_LEN1_SHIFT) & 15u;
-        uint32_t syms = e;  // byte 0 = first symbol, byte 1 = second
-        // the pair is usable only if the second symbol also begins before `end`
-        bool two = ((e >> LUT_TWO_SHIFT) & 1u) && pos + lut_bits <= end;
-        uint32_t len = two ? ((e >> LUT_LEN2_SHIFT) & 15u) : len1;
-        bool valid = true;
-        if (len1 == 0) {  // longer than lut_bits, or no codeword at all
-            const uint32_t window = static_cast<uint32_t>(buf >> 32);
-            valid = false;
-            two = false;
-            len = 1;  // not a codeword (only on a wrong guess or a malformed stream): resynchronise bit by bit
-            uint32_t hit = 0;
-            if ((e >> LUT_SUB_SHIFT) & 1u)
-                hit = m.sub[((e & 0xffu) << tb.sub_bits) | ((window << lut_bits) >> (32 - tb.sub_bits))];
-            if (hit == 0) {  // deeper than both tables (or no table slot left): search the list
-                for (uint32_t i = 0; i < tb.n_long; ++i) {
-                    const uint32_t meta = m.longc[2 * i + 1], l = meta >> 8;
-                    if (((window ^ m.longc[2 * i]) >> (32 - l)) == 0) {
-                        hit = meta;
-                        break;
-                    }
-                }
-            }
-            if (hit) {
-                len = hit >> 8;
-                syms = hit & 0xffu;
-                valid = true;
-            }
-        }
-        if (pos + len > lim) {  // only ever true in the stream's last subsequences
-            if (two && pos + len1 <= lim) {
-                two = false;
-                len = len1;
-            } else {
-                pos = end;  // ran off the stream: nothing further begins here
+    SubResult res;
+    res.start_rel = start_rel;
+
+    const uint32_t k0 = pos >> 5;
+    uint32_t sh = pos & 31;
+    const uint32_t k1 = k0 + (sh != 0);
+    uint32_t r0 = m.sdata[phys(k0)];
+    uint32_t r1 = m.sdata[phys(k1)];
+    uint32_t next_word = k1 + 1;
+    uint32_t r2 = m.sdata[phys(next_word)];
+    sh = sh ? sh : 32;  // sh == 32: the window is exactly r1
+
+#define ET_ADVANCE(len_)                          \
+    do {                                          \
+        pos += (len_);                            \
+        sh += (len_);                             \
+        const bool rotate_ = sh > 32;             \
+        r0 = rotate_ ? r1 : r0;                   \
+        r1 = rotate_ ? r2 : r1;                   \
+        sh = rotate_ ? sh - 32 : sh;              \
+        next_word += rotate_;                     \
+        r2 = m.sdata[phys(next_word)];            \
+    } while (0)
+
+    if (WARM) {
+        while (pos < begin) {
+            uint32_t syms, n, len1;
+            bool two;
+            const uint32_t len = table_step(m, tb, __builtin_amdgcn_alignbit(r0, r1, 32 - sh), false, syms, n, two, len1);
+            if (CHECK_LIM && pos + len > lim) {
+                pos = end;  // the stream ends before this subsequence
                 break;
             }
+            ET_ADVANCE(len);
         }
-        if (valid) {
-            if (WRITE == 1) {
-                const uint32_t o = stage_pos + count;
-                m.stage[o] = static_cast<uint8_t>(syms);
-                if (two) m.stage[o + 1] = static_cast<uint8_t>(syms >> 8);
-            } else if (WRITE == 2) {
-                const uint32_t o = stage_pos + count;
-                if (o >= stage_lo && o < stage_hi) m.stage[o - stage_lo] = static_cast<uint8_t>(syms);
-                if (two && o + 1 >= stage_lo && o + 1 < stage_hi) m.stage[o + 1 - stage_lo] = static_cast<uint8_t>(syms >> 8);
-            }
-            count += two ? 2u : 1u;
-        }
-        pos += len;
-        buf <<= len;
-        avail -= len;
-        if (avail < 32) {
-            buf |= static_cast<unsigned long long>(m.sdata[phys(next_word)]) << (32 - avail);
-            avail += 32;
-            ++next_word;
-        }
+        res.start_rel = pos < end ? pos - begin : 0u;
     }
-    SubResult r;
-    r.exit_rel = pos - end;
-    r.count = count;
-    return r;
+    while (pos < end) {
+        uint32_t syms, n, len1;
+        bool two;
+        // the pair is usable only if the second symbol also begins before `end`
+        uint32_t len = table_step(m, tb, __builtin_amdgcn_alignbit(r0, r1, 32 - sh), pos <= end_two, syms, n, two, len1);
+        if (CHECK_LIM) {
+            if (pos + len > lim) {
+                if (two && pos + len1 <= lim) {
+                    two = false;
+                    len = len1;
+                    n = 1;
+                } else {
+                    pos = end;  // ran off the stream: nothing further begins here
+                    break;
+                }
+            }
+        }
+        if (WRITE == 1) {
+            const uint32_t o = stage_pos + count;
+            m.stage[o] = static_cast<uint8_t>(syms);
+            m.stage[two ? o + 1 : dummy] = static_cast<uint8_t>(syms >> 8);
+        } else if (WRITE == 2) {
+            const uint32_t o = stage_pos + count;
+            if (n && o >= stage_lo && o < stage_hi) m.stage[o - stage_lo] = static_cast<uint8_t>(syms);
+            if (two && o + 1 >= stage_lo && o + 1 < stage_hi) m.stage[o + 1 - stage_lo] = static_cast<uint8_t>(syms >> 8);
+        }
+        count += n;
+        ET_ADVANCE(len);
+    }
+#undef ET_ADVANCE
+    res.exit_rel = pos - end;
+    res.count = count;
+    return res;
 }
 
 __device__ __forceinline__ uint32_t block_limit(uint64_t n_bytes, uint64_t block) {
-    const uint64_t rel = n_bytes * 8 - block * DEC_BLOCK_WORDS * 32;
+    const uint64_t rel = n_bytes * 8 - block * DEC_BLOCK_WORDS * 32 + DEC_WARMUP_BITS;  // same origin as walk_subsequence
     return rel > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(rel);
 }
 
@@ -613,9 +662,10 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
     const bool live = sub_g < n_subs;
 
     uint32_t start, exit_rel = 0, count = 0;
-    bool need;
+    bool need, warm = false;
     if (iter == 0) {
-        start = (sub_g == 0) ? first_bit : 0u;
+        start = first_bit;   // exact for the stream's first subsequence; every other one runs in
+        warm = sub_g != 0;
         need = live;
     } else {
         const uint32_t st = live ? sub_state[sub_g] : 0u;
@@ -637,11 +687,16 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
     __syncthreads();
 
     const uint32_t lim = block_limit(n_bytes, b);
+    const bool near_end = lim < DEC_STAGED_WORDS * 32 + 64;  // workgroup-uniform: the stream ends in (or just after) this block
     for (;;) {
         if (need) {
-            const SubResult r = walk_subsequence<0>(m, tb, tid, start, lim, 0, 0, 0);
+            SubResult r;
+            if (warm) r = near_end ? walk_subsequence<0, true, true>(m, tb, tid, 0, lim, 0, 0, 0) : walk_subsequence<0, false, true>(m, tb, tid, 0, lim, 0, 0, 0);
+            else r = near_end ? walk_subsequence<0, true, false>(m, tb, tid, start, lim, 0, 0, 0) : walk_subsequence<0, false, false>(m, tb, tid, start, lim, 0, 0, 0);
+            start = r.start_rel;
             exit_rel = r.exit_rel;
             count = r.count;
+            warm = false;
         }
         m.exits[tid] = exit_rel;
         __syncthreads();
@@ -717,13 +772,14 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
     // stage positions are `phase + symbol index`; windows of DEC_STAGE_BYTES of them.
     // Usual case: the workgroup's symbols fit one window and none is clamped away.
     const bool one_window = phase + block_total <= DEC_STAGE_BYTES && n_out == block_total;
+    const bool near_end = lim < DEC_STAGED_WORDS * 32 + 64;
     for (uint32_t win = 0; win < phase + n_out; win += DEC_STAGE_BYTES) {
         const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
         const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
-        if (one_window) {
-            if (live && count) walk_subsequence<1>(m, tb, tid, start, lim, my_lo, 0, 0);
+        if (one_window && !near_end) {
+            if (live && count) walk_subsequence<1, false, false>(m, tb, tid, start, lim, my_lo, 0, 0);
         } else if (live && my_lo < win_hi && my_hi > win) {
-            walk_subsequence<2>(m, tb, tid, start, lim, my_lo, win, win_hi);
+            walk_subsequence<2, true, false>(m, tb, tid, start, lim, my_lo, win, win_hi);
         }
         __syncthreads();
         const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
@@ -743,7 +799,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
 // --------------------------------------------------------------------------------
 static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage) {
     const uint32_t sub_w = (((tb.n_sub << tb.sub_bits) + 7u) & ~7u) / 2;
-    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + 512 + sub_w + BLOCK + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES : 0);
+    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + sub_w + BLOCK + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 + BLOCK * 4 : 0);
 }
 
 static inline uint32_t hist_grid(uint32_t n_tiles) { return n_tiles < MAX_GRID ? n_tiles : MAX_GRID; }
