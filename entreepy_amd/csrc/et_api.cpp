@@ -43,7 +43,7 @@ struct et_ctx {
     std::string err;
 
     // encode workspaces
-    DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, len_table;
+    DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, len_table, group_sum;
     // decode workspaces
     DevBuf sub_state, blk_exit, blk_count, blk_off, lut, longc, subt, flag;
     // staging for the host-pointer entry points
@@ -157,6 +157,7 @@ int ensure_encode_ws(et_ctx *ctx, uint32_t n_tiles) {
     ET_TRY(ensure(ctx, ctx->tile_off, (static_cast<size_t>(n_tiles) + 1) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->enc_table, 256 * 2 * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->len_table, 256 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_tiles) / 1024 + 2) * sizeof(uint64_t)));
     return ET_OK;
 }
 
@@ -203,7 +204,8 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
     ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     ET_HIP(hipMemcpyAsync(ctx->len_table.p, ctx->h_len, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     et::launch_tile_scan(ctx->stream, static_cast<const uint32_t *>(ctx->tile_hist.p), g.n_tiles,
-                         static_cast<const uint32_t *>(ctx->len_table.p), static_cast<unsigned long long *>(ctx->tile_bits.p), base_bit,
+                         static_cast<const uint32_t *>(ctx->len_table.p), static_cast<unsigned long long *>(ctx->tile_bits.p),
+                         static_cast<unsigned long long *>(ctx->group_sum.p), base_bit,
                          static_cast<unsigned long long *>(ctx->tile_off.p), out32);
     ET_HIP(hipGetLastError());
     if (header_len) {
@@ -287,7 +289,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->len_table,
+    DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->len_table, &ctx->group_sum,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->longc, &ctx->subt, &ctx->flag,
                       &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
@@ -352,6 +354,7 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->blk_exit, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_count, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (n_blocks + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->group_sum, (n_blocks / 1024 + 2) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->lut, sizeof(uint32_t) << et::DEC_LUT_BITS_MAX));
     ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->subt, SUB_TABLE_BYTES));
@@ -638,7 +641,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     record(ctx, 1);
 
     // D2
-    et::launch_dec_scan(ctx->stream, blk_count, n_blocks, blk_off);
+    ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
+    et::launch_dec_scan(ctx->stream, blk_count, n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), blk_off);
     ET_HIP(hipGetLastError());
     ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     record(ctx, 2);

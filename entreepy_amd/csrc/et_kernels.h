@@ -46,13 +46,15 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist);
 uint32_t hist_rows(uint32_t n_tiles);
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
-                      unsigned long long *tile_bits, unsigned long long base_bit, unsigned long long *tile_off, uint32_t *out32);
+                      unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
+                      unsigned long long *tile_off, uint32_t *out32);
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32);
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed);
-void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *blk_off);
+void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
+                     unsigned long long *blk_off);
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out);

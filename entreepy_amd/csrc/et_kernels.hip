@@ -3,10 +3,10 @@
 // LDS pipe (atomics + table reads) and VALU issue.
 //
 //   encode.zig:43-47   -> k_hist_tiles (+ k_hist_reduce)          "K1"
-//   encode.zig:308-313 -> k_tile_bits, k_tile_scan                "K2" (the serial
+//   encode.zig:308-313 -> k_tile_bits, k_scan_local/_finish       "K2" (the serial
 //                         bits_written counter turned into a scan over tiles)
 //   encode.zig:303-315 -> k_encode_tiles / k_encode_tiles_long    "K4"
-//   decode.zig:143-203 -> k_dec_sync, k_dec_scan, k_dec_write     "D1..D3"
+//   decode.zig:143-203 -> k_dec_sync, k_scan_*, k_dec_write       "D1..D3"
 //
 // Geometry shared by every kernel: workgroups of 256 threads (4 wavefronts of 64).
 // Encode side: a "round" is 4 KiB of input, one 16-byte load per lane, fully
@@ -200,38 +200,52 @@ __global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict_
     }
 }
 
-// Single-workgroup exclusive scan: tile_off[t] = base_bit + sum(tile_bits[0..t)),
-// tile_off[n_tiles] = end bit.  Also zeroes every 32-bit output word that holds a
-// tile boundary: those are the only words two workgroups of K4 may share, and K4
-// merges into them with atomicOr.
-__global__ __launch_bounds__(1024) void k_tile_scan(const unsigned long long *__restrict__ tile_bits, uint32_t n_tiles,
-                                                    unsigned long long base_bit, unsigned long long *__restrict__ tile_off,
-                                                    uint32_t *__restrict__ out32) {
+// Two-level exclusive scan over n values (tile bit totals / workgroup symbol counts):
+// k_scan_local scans groups of 1024 in one workgroup each and leaves the group sums;
+// k_scan_finish adds base + the sums of all earlier groups, writes out[n] = grand
+// total and, for the encoder, zeroes every 32-bit output word that holds a tile
+// boundary: those are the only words two workgroups of K4 may share, and K4 merges
+// into them with atomicOr.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out,
+                                                     unsigned long long *__restrict__ group_sum) {
     __shared__ unsigned long long wsum[16];
-    __shared__ unsigned long long carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = base_bit;
+    const uint32_t i = blockIdx.x * 1024 + tid;
+    const unsigned long long x = (i < n) ? static_cast<unsigned long long>(in[i]) : 0ull;
+    const unsigned long long inc = wave_inclusive_scan64(x);
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    for (uint32_t c0 = 0; c0 < n_tiles; c0 += 1024) {
-        const uint32_t t = c0 + tid;
-        const unsigned long long x = (t < n_tiles) ? tile_bits[t] : 0ull;
-        const unsigned long long inc = wave_inclusive_scan64(x);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned long long before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        const unsigned long long excl = before + inc - x;
-        if (t < n_tiles) {
-            tile_off[t] = excl;
-            out32[excl >> 5] = 0;
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = before + inc;
-        __syncthreads();
+    unsigned long long before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (i < n) out[i] = before + inc - x;
+    if (tid == 1023) group_sum[blockIdx.x] = before + inc;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__restrict__ out, uint32_t n,
+                                                      const unsigned long long *__restrict__ group_sum, unsigned long long base,
+                                                      uint32_t *__restrict__ zero_words) {
+    __shared__ unsigned long long wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = blockIdx.x;
+    unsigned long long part = 0;
+    for (uint32_t j = tid; j < g; j += 1024) part += group_sum[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    unsigned long long prefix = base;
+    for (int w = 0; w < 16; ++w) prefix += wsum[w];
+    const uint32_t i = g * 1024 + tid;
+    if (i < n) {
+        const unsigned long long v = out[i] + prefix;
+        out[i] = v;
+        if (zero_words) zero_words[v >> 5] = 0;
     }
-    if (tid == 0) {
-        tile_off[n_tiles] = carry_s;
-        out32[carry_s >> 5] = 0;
+    if (g == gridDim.x - 1 && tid == 0) {
+        const unsigned long long total = prefix + group_sum[g];
+        out[n] = total;
+        if (zero_words) zero_words[total >> 5] = 0;
     }
 }
 
@@ -717,29 +731,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
     if (tid == static_cast<int>(last_live)) blk_exit[b] = exit_rel;
 }
 
-// D2: single-workgroup exclusive scan of blk_count -> blk_off (u64), total at [n].
-__global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *__restrict__ blk_count, uint32_t n_blocks,
-                                                   unsigned long long *__restrict__ blk_off) {
-    __shared__ unsigned long long wsum[16];
-    __shared__ unsigned long long carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < n_blocks; c0 += 1024) {
-        const uint32_t i = c0 + tid;
-        const unsigned long long x = (i < n_blocks) ? blk_count[i] : 0ull;
-        const unsigned long long inc = wave_inclusive_scan64(x);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned long long before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (i < n_blocks) blk_off[i] = before + inc - x;
-        __syncthreads();
-        if (tid == 1023) carry_s = before + inc;
-        __syncthreads();
-    }
-    if (tid == 0) blk_off[n_blocks] = carry_s;
-}
+// D2 (scan of the workgroup symbol counts) is k_scan_local / k_scan_finish above.
 
 // D3: decode every subsequence from its synchronised start and write the symbols.
 // Symbols are staged in LDS so that the workgroup's contiguous output range leaves
@@ -816,11 +808,14 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
 uint32_t hist_rows(uint32_t n_tiles) { return hist_grid(n_tiles); }
 
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
-                      unsigned long long *tile_bits, unsigned long long base_bit, unsigned long long *tile_off, uint32_t *out32) {
+                      unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
+                      unsigned long long *tile_off, uint32_t *out32) {
     uint32_t grid = (n_tiles + 3) / 4;
     if (grid > MAX_GRID) grid = MAX_GRID;
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, tile_bits, n_tiles, base_bit, tile_off, out32);
+    const uint32_t groups = (n_tiles + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum);
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32);
 }
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
@@ -841,8 +836,11 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
     hipLaunchKernelGGL(k_dec_sync, dim3(n_blocks), dim3(BLOCK), decode_smem_bytes(tb, false), stream, words, n_bytes, first_bit, n_subs, tb, iter, sub_state, blk_exit, blk_count, changed);
 }
 
-void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *blk_off) {
-    hipLaunchKernelGGL(k_dec_scan, dim3(1), dim3(1024), 0, stream, blk_count, n_blocks, blk_off);
+void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
+                     unsigned long long *blk_off) {
+    const uint32_t groups = (n_blocks + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum);
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr));
 }
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
