@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libentreepy_hip.so")
+# ET_LIB_PATH: load another build of the same library (A/B variants in tools/ab_variants.sh)
+LIB_PATH = os.environ.get("ET_LIB_PATH") or os.path.join(_HERE, "libentreepy_hip.so")
 
 ET_OK, ET_ERR_EMPTY, ET_ERR_NOMEM, ET_ERR_CAP, ET_ERR_FORMAT, ET_ERR_HIP, ET_ERR_ARG, ET_ERR_UNSUPPORTED = range(8)
 

@@ -625,12 +625,12 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
 
     // D1: sweep 0 guesses, later sweeps repair; stop after a sweep that changed nothing.
     uint32_t iters = 0;
-    et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, sub_state, blk_exit, blk_count, flag);
+    et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, sub_state, blk_exit, blk_count, flag, flag + 4);
     ET_HIP(hipGetLastError());
     ++iters;
     for (;;) {
         ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, sub_state, blk_exit, blk_count, flag);
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, sub_state, blk_exit, blk_count, flag, flag + 4);
         ET_HIP(hipGetLastError());
         ++iters;
         ET_HIP(hipMemcpyAsync(ctx->h_scalar, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -653,7 +653,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
 
     // D3
     if (n_out) {
-        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out));
+        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out), flag + 4);
         ET_HIP(hipGetLastError());
     }
     record(ctx, 3);

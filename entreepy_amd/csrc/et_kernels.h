@@ -14,6 +14,21 @@ constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-st
 constexpr uint32_t SUB_BITS = 256;                             // decode: bits per lane subsequence
 constexpr uint32_t DEC_BLOCK_WORDS = BLOCK * SUB_BITS / 32;    // 8 KiB of bitstream per workgroup
 constexpr uint32_t DEC_GUARD_WORDS = 4;                        // words a lane may read past its workgroup's 8 KiB
+// How the decode kernels take their 8 KiB blocks (measured choices; -D overrides for A/B builds):
+#ifndef ET_SYNC_CHUNK
+#define ET_SYNC_CHUNK 1
+#endif
+#ifndef ET_SYNC_TICKET
+#define ET_SYNC_TICKET 0
+#endif
+#ifndef ET_WRITE_CHUNK
+#define ET_WRITE_CHUNK 8
+#endif
+#ifndef ET_WRITE_TICKET
+#define ET_WRITE_TICKET 1
+#endif
+constexpr uint32_t SYNC_CHUNK = ET_SYNC_CHUNK, WRITE_CHUNK = ET_WRITE_CHUNK;  // consecutive blocks per chunk
+constexpr bool SYNC_TICKET = ET_SYNC_TICKET, WRITE_TICKET = ET_WRITE_TICKET;  // chunks by ticket counter vs one per workgroup
 constexpr uint32_t DEC_FRONT_WORDS = 4;                        // words staged BEFORE the workgroup's 8 KiB (warm-up run-in)
 constexpr uint32_t DEC_WARMUP_BITS = DEC_FRONT_WORDS * 32;     // run-in before each subsequence in the first sync sweep
 constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GUARD_WORDS;
@@ -52,11 +67,11 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32);
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter,
-                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed);
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket);
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
                      unsigned long long *blk_off);
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
-                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out);
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket);
 
 }  // namespace et

@@ -498,19 +498,46 @@ __device__ __forceinline__ uint32_t load_be32_guarded(const uint32_t *__restrict
     return v;
 }
 
-// Stage the workgroup's 8 KiB of bitstream (+ guard words) into LDS as host-order
-// words whose numeric MSB is the first stream bit, and the lookup tables next to it.
-__device__ __forceinline__ void stage_block(const DecodeSmem &m, const DecodeTables &tb, const uint32_t *__restrict__ words,
-                                            uint64_t first_word, uint64_t n_bytes) {
-    // logical word i of the stage = stream word first_word - DEC_FRONT_WORDS + i (zero before the stream)
-    for (uint32_t i = threadIdx.x; i < DEC_STAGED_WORDS; i += BLOCK) {
-        const bool before = first_word + i < DEC_FRONT_WORDS;
-        m.sdata[phys(i)] = before ? 0u : load_be32_guarded(words, first_word + i - DEC_FRONT_WORDS, n_bytes);
-    }
+// Staging.  A decode workgroup handles a chunk of DEC_CHUNK_BLOCKS consecutive 8 KiB
+// blocks: it copies the lookup tables into LDS once and then walks the blocks; while it
+// works on one block, the next block's words are already in flight into registers
+// (prefetch_block) and are written to LDS (commit_block) only when the current block
+// is done with the staging area.  LDS holds host-order words whose numeric MSB is the
+// first stream bit; logical word i of the stage = stream word
+// first_word - DEC_FRONT_WORDS + i (zero before and after the stream).
+constexpr int DEC_WORDS_PER_THREAD = (DEC_STAGED_WORDS + BLOCK - 1) / BLOCK;
+
+struct Prefetch {
+    uint32_t w[DEC_WORDS_PER_THREAD];
+};
+
+__device__ __forceinline__ void stage_tables(const DecodeSmem &m, const DecodeTables &tb) {
     const uint32_t n_lut = 1u << tb.lut_bits;
     for (uint32_t i = threadIdx.x; i < n_lut; i += BLOCK) m.lut[i] = tb.lut[i];
     const uint32_t n_sub_words = sub_words(tb);
     for (uint32_t i = threadIdx.x; i < n_sub_words; i += BLOCK) reinterpret_cast<uint32_t *>(m.sub)[i] = reinterpret_cast<const uint32_t *>(tb.sub)[i];
+}
+
+__device__ __forceinline__ void prefetch_block(Prefetch &p, const uint32_t *__restrict__ words, uint64_t block, uint64_t n_bytes) {
+    const uint64_t first_word = block * DEC_BLOCK_WORDS;
+    // workgroup-uniform: every staged word lies wholly inside the stream
+    const bool interior = first_word >= DEC_FRONT_WORDS && (first_word - DEC_FRONT_WORDS + DEC_STAGED_WORDS) * 4 <= n_bytes;
+#pragma unroll
+    for (int j = 0; j < DEC_WORDS_PER_THREAD; ++j) {
+        const uint32_t i = j * BLOCK + threadIdx.x;
+        if (i < DEC_STAGED_WORDS) {
+            if (interior) p.w[j] = __builtin_bswap32(words[first_word - DEC_FRONT_WORDS + i]);
+            else p.w[j] = (first_word + i < DEC_FRONT_WORDS) ? 0u : load_be32_guarded(words, first_word + i - DEC_FRONT_WORDS, n_bytes);
+        }
+    }
+}
+
+__device__ __forceinline__ void commit_block(const DecodeSmem &m, const Prefetch &p) {
+#pragma unroll
+    for (int j = 0; j < DEC_WORDS_PER_THREAD; ++j) {
+        const uint32_t i = j * BLOCK + threadIdx.x;
+        if (i < DEC_STAGED_WORDS) m.sdata[phys(i)] = p.w[j];
+    }
 }
 
 struct SubResult {
@@ -558,8 +585,8 @@ __device__ __forceinline__ uint32_t table_step(const DecodeSmem &m, const Decode
 //   WARM: start DEC_WARMUP_BITS before the subsequence and run in (single symbols,
 //         nothing counted); the first codeword boundary at or after the subsequence's
 //         first bit becomes start_rel.  Otherwise start at the given start_rel.
-//   `lim` = stream end (same origin, clamped to u32), tested only when CHECK_LIM (the
-//         stream's last workgroup).
+//   `lim` = stream end (same origin), tested only when CHECK_LIM (the block(s) the
+//         stream ends in): a test with a `break` in the hot loop costs ~25 % everywhere.
 // A symbol belongs to the subsequence in which it BEGINS.
 //
 // The loop bodies are written without divergent branches (one scalar unit serves the
@@ -623,16 +650,14 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
         bool two;
         // the pair is usable only if the second symbol also begins before `end`
         uint32_t len = table_step(m, tb, __builtin_amdgcn_alignbit(r0, r1, 32 - sh), pos <= end_two, syms, n, two, len1);
-        if (CHECK_LIM) {
-            if (pos + len > lim) {
-                if (two && pos + len1 <= lim) {
-                    two = false;
-                    len = len1;
-                    n = 1;
-                } else {
-                    pos = end;  // ran off the stream: nothing further begins here
-                    break;
-                }
+        if (CHECK_LIM && pos + len > lim) {  // only ever true in the stream's last block
+            if (two && pos + len1 <= lim) {
+                two = false;
+                len = len1;
+                n = 1;
+            } else {
+                pos = end;  // ran off the stream: nothing further begins here
+                break;
             }
         }
         if (WRITE == 1) {
@@ -655,80 +680,117 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
 
 __device__ __forceinline__ uint32_t block_limit(uint64_t n_bytes, uint64_t block) {
     const uint64_t rel = n_bytes * 8 - block * DEC_BLOCK_WORDS * 32 + DEC_WARMUP_BITS;  // same origin as walk_subsequence
-    return rel > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(rel);
+    // UINT32_MAX unless the stream ends inside (or just after) the staged words of this block
+    return rel < DEC_STAGED_WORDS * 32 + 64 ? static_cast<uint32_t>(rel) : 0xffffffffu;
 }
 
-// D1.  iter == 0: every subsequence guesses that a codeword begins at its first bit
-// (the very first one starts at first_bit, which is exact).  iter > 0: a workgroup
-// whose predecessor's exit still equals the start its lane 0 used returns at once;
-// otherwise it re-runs its local fixed point from the stored state and raises
-// *changed.  blk_exit[b] is read by workgroup b+1 of the SAME launch without
-// ordering: either value is a legal intermediate state, and a launch that ends with
-// *changed == 0 has seen every workgroup consistent with its predecessor.
+// D1.  FIRST sweep: every subsequence runs in over the DEC_WARMUP_BITS before it (the
+// stream's very first one starts at first_bit, which is exact); lanes whose run-in
+// disagrees with their predecessor's exit are re-walked until the workgroup is
+// consistent.  Later sweeps: a block whose predecessor's exit still equals the start
+// its lane 0 used is skipped; otherwise its local fixed point is redone from the
+// stored state and *changed is raised.  blk_exit[b] may be read by the workgroup
+// handling block b+1 in the SAME launch without ordering: either value is a legal
+// intermediate state, and a launch that ends with *changed == 0 has seen every block
+// consistent with its predecessor.
+template <bool FIRST>
 __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit,
-                                                    uint64_t n_subs, DecodeTables tb, uint32_t iter,
+                                                    uint64_t n_subs, uint32_t n_blocks, DecodeTables tb,
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
-                                                    uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed) {
+                                                    uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed,
+                                                    uint32_t *__restrict__ ticket) {
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
-    const uint64_t b = blockIdx.x;
-    const uint64_t sub_g = b * BLOCK + tid;
-    const bool live = sub_g < n_subs;
-
-    uint32_t start, exit_rel = 0, count = 0;
-    bool need, warm = false;
-    if (iter == 0) {
-        start = first_bit;   // exact for the stream's first subsequence; every other one runs in
-        warm = sub_g != 0;
-        need = live;
-    } else {
-        const uint32_t st = live ? sub_state[sub_g] : 0u;
-        start = st & 0xffu;
-        exit_rel = (st >> 8) & 0xffu;
-        count = st >> 16;
-        need = false;
-        if (tid == 0) {
-            const uint32_t in = (b == 0) ? first_bit : blk_exit[b - 1];
-            need = in != start;
-            start = in;
-            m.scratch[4] = need;
+    stage_tables(m, tb);
+    Prefetch pf;
+    uint32_t round = 0;
+    // Blocks are handed out in chunks of SYNC_CHUNK consecutive blocks (tables staged
+    // once per workgroup, next block prefetched inside a chunk): either one chunk per
+    // workgroup, dispatched by the hardware, or (SYNC_TICKET) through a ticket counter
+    // to a grid sized to the device, so that a workgroup that becomes resident late --
+    // or never -- costs nothing.
+    for (bool first_trip = true;; first_trip = false) {
+        uint64_t b0;
+        if (SYNC_TICKET) {
+            __syncthreads();  // tables staged (first trip); everybody is done with scratch[7]
+            if (tid == 0) m.scratch[7] = atomicAdd(ticket, SYNC_CHUNK);
+            __syncthreads();
+            b0 = m.scratch[7];
+        } else {
+            if (!first_trip) break;
+            b0 = static_cast<uint64_t>(blockIdx.x) * SYNC_CHUNK;
+            __syncthreads();
+        }
+        if (b0 >= n_blocks) break;
+        const uint64_t b1 = b0 + SYNC_CHUNK < n_blocks ? b0 + SYNC_CHUNK : n_blocks;
+        if (FIRST) prefetch_block(pf, words, b0, n_bytes);
+    for (uint64_t b = b0; b < b1; ++b, ++round) {
+        const uint64_t sub_g = b * BLOCK + tid;
+        const bool live = sub_g < n_subs;
+        uint32_t start, exit_rel = 0, count = 0;
+        bool need, warm = false;
+        if (FIRST) {
+            start = first_bit;  // exact for the stream's first subsequence; every other one runs in
+            warm = sub_g != 0;
+            need = live;
+            commit_block(m, pf);
+            if (b + 1 < b1) prefetch_block(pf, words, b + 1, n_bytes);
+        } else {
+            const uint32_t st = live ? sub_state[sub_g] : 0u;
+            start = st & 0xffu;
+            exit_rel = (st >> 8) & 0xffu;
+            count = st >> 16;
+            need = false;
+            uint32_t *flag = m.scratch + 4 + (round & 1);
+            if (tid == 0) {
+                const uint32_t in = (b == 0) ? first_bit : blk_exit[b - 1];
+                need = in != start;
+                start = in;
+                *flag = need;
+            }
+            __syncthreads();
+            if (!*flag) continue;
+            if (tid == 0) *changed = 1;
+            prefetch_block(pf, words, b, n_bytes);
+            commit_block(m, pf);
         }
         __syncthreads();
-        if (!m.scratch[4]) return;
-        if (tid == 0) *changed = 1;
-    }
-    stage_block(m, tb, words, b * DEC_BLOCK_WORDS, n_bytes);
-    __syncthreads();
 
-    const uint32_t lim = block_limit(n_bytes, b);
-    const bool near_end = lim < DEC_STAGED_WORDS * 32 + 64;  // workgroup-uniform: the stream ends in (or just after) this block
-    for (;;) {
-        if (need) {
-            SubResult r;
-            if (warm) r = near_end ? walk_subsequence<0, true, true>(m, tb, tid, 0, lim, 0, 0, 0) : walk_subsequence<0, false, true>(m, tb, tid, 0, lim, 0, 0, 0);
-            else r = near_end ? walk_subsequence<0, true, false>(m, tb, tid, start, lim, 0, 0, 0) : walk_subsequence<0, false, false>(m, tb, tid, start, lim, 0, 0, 0);
-            start = r.start_rel;
-            exit_rel = r.exit_rel;
-            count = r.count;
-            warm = false;
+        const uint32_t lim = block_limit(n_bytes, b);
+        for (;;) {
+            if (need) {
+                SubResult r;
+                if (lim != 0xffffffffu) {  // workgroup-uniform: the stream ends in this block
+                    r = warm ? walk_subsequence<0, true, true>(m, tb, tid, 0, lim, 0, 0, 0) : walk_subsequence<0, true, false>(m, tb, tid, start, lim, 0, 0, 0);
+                } else if (warm) {
+                    r = walk_subsequence<0, false, true>(m, tb, tid, 0, lim, 0, 0, 0);
+                } else {
+                    r = walk_subsequence<0, false, false>(m, tb, tid, start, lim, 0, 0, 0);
+                }
+                start = r.start_rel;
+                exit_rel = r.exit_rel;
+                count = r.count;
+                warm = false;
+            }
+            m.exits[tid] = exit_rel;
+            __syncthreads();
+            need = false;
+            if (tid > 0 && live) {
+                const uint32_t in = m.exits[tid - 1];
+                need = in != start;
+                start = in;
+            }
+            if (!__syncthreads_or(need)) break;
         }
-        m.exits[tid] = exit_rel;
-        __syncthreads();
-        need = false;
-        if (tid > 0 && live) {
-            const uint32_t in = m.exits[tid - 1];
-            need = in != start;
-            start = in;
-        }
-        if (!__syncthreads_or(need)) break;
+        if (live) sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
+        uint32_t total;
+        block_exclusive_scan(live ? count : 0u, m.scratch, &total);
+        if (tid == 0) blk_count[b] = total;
+        // exit of the last live subsequence of this block
+        const uint64_t last_live = (n_subs - b * BLOCK >= BLOCK) ? BLOCK - 1 : (n_subs - b * BLOCK - 1);
+        if (tid == static_cast<int>(last_live)) blk_exit[b] = exit_rel;
     }
-    if (live) sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
-    uint32_t total;
-    block_exclusive_scan(live ? count : 0u, m.scratch, &total);
-    if (tid == 0) blk_count[b] = total;
-    // exit of the last live subsequence of this workgroup
-    const uint64_t last_live = (n_subs - b * BLOCK >= BLOCK) ? BLOCK - 1 : (n_subs - b * BLOCK - 1);
-    if (tid == static_cast<int>(last_live)) blk_exit[b] = exit_rel;
+    }
 }
 
 // D2 (scan of the workgroup symbol counts) is k_scan_local / k_scan_finish above.
@@ -737,52 +799,71 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
 // Symbols are staged in LDS so that the workgroup's contiguous output range leaves
 // as 16-byte stores; stage byte j maps to out byte (o0 & ~15) + j.
 __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict__ words, uint64_t n_bytes, uint64_t n_subs,
-                                                     DecodeTables tb, const uint32_t *__restrict__ sub_state,
+                                                     uint32_t n_blocks, DecodeTables tb, const uint32_t *__restrict__ sub_state,
                                                      const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
-                                                     uint8_t *__restrict__ out) {
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ ticket) {
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
-    const uint64_t b = blockIdx.x;
-    const uint64_t o0 = blk_off[b];
-    if (o0 >= n_symbols) return;  // pad bits decoded past the declared length
-    const uint64_t sub_g = b * BLOCK + tid;
-    const bool live = sub_g < n_subs;
-    const uint32_t st = live ? sub_state[sub_g] : 0u;
-    const uint32_t start = st & 0xffu, count = live ? (st >> 16) : 0u;
-
-    stage_block(m, tb, words, b * DEC_BLOCK_WORDS, n_bytes);
-    uint32_t block_total;
-    const uint32_t my_off = block_exclusive_scan(count, m.scratch, &block_total);  // its barrier also covers the staging
-
-    uint64_t o1 = o0 + block_total;
-    if (o1 > n_symbols) o1 = n_symbols;
-    const uint32_t n_out = static_cast<uint32_t>(o1 - o0);
-    const uint32_t phase = static_cast<uint32_t>(o0 & 15);  // stage offset of the first symbol
-    const uint32_t lim = block_limit(n_bytes, b);
-    uint8_t *out_base = out + (o0 - phase);
-
-    // stage positions are `phase + symbol index`; windows of DEC_STAGE_BYTES of them.
-    // Usual case: the workgroup's symbols fit one window and none is clamped away.
-    const bool one_window = phase + block_total <= DEC_STAGE_BYTES && n_out == block_total;
-    const bool near_end = lim < DEC_STAGED_WORDS * 32 + 64;
-    for (uint32_t win = 0; win < phase + n_out; win += DEC_STAGE_BYTES) {
-        const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
-        const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
-        if (one_window && !near_end) {
-            if (live && count) walk_subsequence<1, false, false>(m, tb, tid, start, lim, my_lo, 0, 0);
-        } else if (live && my_lo < win_hi && my_hi > win) {
-            walk_subsequence<2, true, false>(m, tb, tid, start, lim, my_lo, win, win_hi);
+    stage_tables(m, tb);
+    Prefetch pf;
+    for (bool first_trip = true;; first_trip = false) {  // chunks: see k_dec_sync
+        uint64_t b0;
+        if (WRITE_TICKET) {
+            __syncthreads();  // tables staged (first trip); everybody is done with scratch[7] and the stage
+            if (tid == 0) m.scratch[7] = atomicAdd(ticket, WRITE_CHUNK);
+            __syncthreads();
+            b0 = m.scratch[7];
+        } else {
+            if (!first_trip) break;
+            b0 = static_cast<uint64_t>(blockIdx.x) * WRITE_CHUNK;
+            __syncthreads();
         }
-        __syncthreads();
-        const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
-        for (uint32_t g = win + tid * 16; g < win_hi; g += BLOCK * 16) {
-            if (g >= lo_valid && g + 16 <= win_hi) {
-                *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(m.stage + (g - win));
-            } else {
-                for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = m.stage[k - win];
+        if (b0 >= n_blocks) break;
+        const uint64_t b1 = b0 + WRITE_CHUNK < n_blocks ? b0 + WRITE_CHUNK : n_blocks;
+        prefetch_block(pf, words, b0, n_bytes);
+    for (uint64_t b = b0; b < b1; ++b) {
+        const uint64_t o0 = blk_off[b];
+        if (o0 >= n_symbols) break;  // pad bits decoded past the declared length; offsets only grow from here
+        const uint64_t sub_g = b * BLOCK + tid;
+        const bool live = sub_g < n_subs;
+        const uint32_t st = live ? sub_state[sub_g] : 0u;
+        const uint32_t start = st & 0xffu, count = live ? (st >> 16) : 0u;
+
+        commit_block(m, pf);
+        if (b + 1 < b1) prefetch_block(pf, words, b + 1, n_bytes);
+        uint32_t block_total;
+        const uint32_t my_off = block_exclusive_scan(count, m.scratch, &block_total);  // its barrier also covers the staging
+
+        uint64_t o1 = o0 + block_total;
+        if (o1 > n_symbols) o1 = n_symbols;
+        const uint32_t n_out = static_cast<uint32_t>(o1 - o0);
+        const uint32_t phase = static_cast<uint32_t>(o0 & 15);  // stage offset of the first symbol
+        const uint32_t lim = block_limit(n_bytes, b);
+        uint8_t *out_base = out + (o0 - phase);
+
+        // stage positions are `phase + symbol index`; windows of DEC_STAGE_BYTES of them.
+        // Usual case: the block's symbols fit one window and none is clamped away.
+        const bool one_window = phase + block_total <= DEC_STAGE_BYTES && n_out == block_total;
+        for (uint32_t win = 0; win < phase + n_out; win += DEC_STAGE_BYTES) {
+            const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
+            const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
+            if (one_window && lim == 0xffffffffu) {
+                if (live && count) walk_subsequence<1, false, false>(m, tb, tid, start, lim, my_lo, 0, 0);
+            } else if (live && my_lo < win_hi && my_hi > win) {
+                walk_subsequence<2, true, false>(m, tb, tid, start, lim, my_lo, win, win_hi);
             }
+            __syncthreads();
+            const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
+            for (uint32_t g = win + tid * 16; g < win_hi; g += BLOCK * 16) {
+                if (g >= lo_valid && g + 16 <= win_hi) {
+                    *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(m.stage + (g - win));
+                } else {
+                    for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = m.stage[k - win];
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    }
     }
 }
 
@@ -829,11 +910,29 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
         hipLaunchKernelGGL(k_encode_tiles<8192>, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
 }
 
+// Grid of a chunked decode kernel: one workgroup per chunk, or -- ticketed -- as many
+// workgroups as the occupancy API reports resident (an over-estimate is harmless).
+template <typename K>
+static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticketed) {
+    if (!ticketed) return n_chunks;
+    int dev = 0, cus = 256, per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint32_t g = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
+    return n_chunks < g ? (n_chunks ? n_chunks : 1) : g;
+}
+
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter,
-                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed) {
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_dec_sync, dim3(n_blocks), dim3(BLOCK), decode_smem_bytes(tb, false), stream, words, n_bytes, first_bit, n_subs, tb, iter, sub_state, blk_exit, blk_count, changed);
+    const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
+    const size_t smem = decode_smem_bytes(tb, false);
+    if (SYNC_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+    if (iter == 0)
+        hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket);
+    else
+        hipLaunchKernelGGL(k_dec_sync<false>, dim3(decode_grid(k_dec_sync<false>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket);
 }
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
@@ -845,9 +944,12 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
-                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out) {
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_dec_write, dim3(n_blocks), dim3(BLOCK), decode_smem_bytes(tb, true), stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_symbols, out);
+    const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
+    const size_t smem = decode_smem_bytes(tb, true);
+    if (WRITE_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket);
 }
 
 }  // namespace et
