@@ -82,7 +82,7 @@ class ShardedCodec:
             if hdr is None:
                 cbk, _, off = _parse_device_header(enc, et_len)
                 hdr = self._hdr_len[et_len] = off + 4
-            return {"world": 1, "n": n, "et_len": et_len, "header_len": hdr, "body_bytes": et_len - hdr,
+            return {"world": 1, "single": True, "n": n, "et_len": et_len, "header_len": hdr, "body_bytes": et_len - hdr,
                     "timings": {"hist": t["hist_ms"], "enc_host": t["host_ms"], "enc_scan": t["scan_ms"], "enc_body": t["body_ms"],
                                 "enc_total": t["total_ms"], "exchange": 0.0}}
 
@@ -119,7 +119,7 @@ class ShardedCodec:
         if enc.is_cuda:
             torch.cuda.synchronize(self.device)
         t_end = time.perf_counter()
-        return {"world": self.world, "n": n, "codebook": cb, "header_len": len(header) if r == 0 else 0, "starts": starts,
+        return {"world": self.world, "single": False, "n": n, "codebook": cb, "header_len": len(header) if r == 0 else 0, "starts": starts,
                 "local_start_bit": local_start, "end_bit": end, "body_bytes": (starts[r + 1] - starts[r] + 7) // 8,
                 "timings": {"hist": hist_ms, "enc_host": (t_h1 - t_x1) * 1e3, "enc_scan": t.get("scan_ms", 0.0), "enc_body": t.get("body_ms", 0.0),
                             "enc_total": (t_end - t_begin) * 1e3, "exchange": (t_x1 - t_x0 + t_end - t_x2) * 1e3}}
@@ -131,7 +131,7 @@ class ShardedCodec:
         with several, every rank decodes its own bit range [S_r, S_{r+1}) using the
         offsets the encode step produced (an in-memory pipeline, not a cold .et read)."""
         ctx = self.ctx
-        if layout["world"] == 1:
+        if layout["single"]:
             return ctx.decode_device(enc[4 : layout["et_len"]], dec)
         start = layout["local_start_bit"]
         byte0 = start // 8
@@ -141,7 +141,7 @@ class ShardedCodec:
     # ------------------------------------------------------------------ concat
     def gather_file(self, enc, layout):
         """Bit-offset-adjusted concatenation on rank 0 -> bytes (None elsewhere)."""
-        if layout["world"] == 1:
+        if layout["single"]:
             return enc[: layout["et_len"]].cpu().numpy().tobytes()
         starts, r = layout["starts"], self.rank
         lo, _ = piece_words(starts, r)

@@ -1,0 +1,143 @@
+"""GPU: the C++ `entreepy` CLI (main.zig surface) and the torch.distributed (RCCL) sharded path."""
+import hashlib
+import os
+import socket
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import corpus
+from tests.conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "entreepy_amd", "entreepy")
+
+
+def test_cli_compress_decompress_round_trip(tmp_path, res_files):
+    from oracle import oracle as O
+
+    for name, text in res_files.items():
+        src = tmp_path / name
+        src.write_bytes(text)
+        et = tmp_path / (name + ".et")
+        r = subprocess.run([EXE, "c", str(src), "-o", str(et)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert et.read_bytes() == O.encode(text)
+        with open(os.path.join(GOLDEN, name + ".et"), "rb") as f:
+            assert et.read_bytes() == f.read()
+        assert r.stderr.strip() == f"{O.format_file_size(len(text))} => {O.format_file_size(et.stat().st_size)}"  # encode.zig:334
+        back = tmp_path / ("back_" + name)
+        r = subprocess.run([EXE, "d", str(et), "-o", str(back)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert back.read_bytes() == text
+        assert r.stderr.strip() == f"{O.format_file_size(et.stat().st_size - 4)} => {O.format_file_size(len(text))}"  # decode.zig:217
+
+
+def test_cli_default_names_dry_run_print_and_debug(tmp_path, res_files):
+    from oracle import oracle as O
+
+    text = res_files["test.txt"]
+    src = tmp_path / "t.txt"
+    src.write_bytes(text)
+    assert subprocess.run([EXE, "compress", str(src)], capture_output=True).returncode == 0  # any word starting with c (main.zig:123)
+    assert (tmp_path / "t.txt.et").read_bytes() == O.encode(text)  # default [file].et (main.zig:156-158)
+    assert subprocess.run([EXE, "d", str(tmp_path / "t.txt.et")], capture_output=True).returncode == 0
+    assert (tmp_path / "decoded_t.txt").read_bytes() == text  # decoded_[file minus .et] (main.zig:159-169)
+    # -t: nothing written; decode reports "=> 0 B" (decode.zig:185-188)
+    out = tmp_path / "never.et"
+    r = subprocess.run([EXE, "-t", "c", str(src), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and not out.exists() and r.stderr.strip() == "47 B => 42 B"
+    r = subprocess.run([EXE, "-t", "d", str(tmp_path / "t.txt.et"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and not out.exists() and r.stderr.strip() == "38 B => 0 B"
+    # -p prints the text (decode.zig:189)
+    r = subprocess.run([EXE, "-pt", "d", str(tmp_path / "t.txt.et")], capture_output=True)
+    assert r.stdout == text
+    # -d: dictionary dump in DFS order (encode.zig:204-212), bits in output, time taken
+    r = subprocess.run([EXE, "-dt", "c", str(src)], capture_output=True)
+    lines = r.stdout.decode("utf-8", "replace").split("\n")
+    _, _, order = O.build_dict(O.histogram(text))
+    want = {"D": "00", "_": "01", "A": "10", "E": "110", "B": "1111", "\n": "11100", "C": "11101"}
+    assert b"\nbits in output: 336\n" in r.stdout and b"time taken: " in r.stdout
+    dump = r.stdout.split(b"\nbits in output")[0]
+    codes = [seg.split(b"\n")[0].decode() for seg in dump.split(b" - ")[1:]]
+    assert codes == [want[chr(s)] for s in order]
+    # empty input: error.QueueEmpty, and the output file has already been created (main.zig:192)
+    empty = tmp_path / "empty.txt"
+    empty.write_bytes(b"")
+    r = subprocess.run([EXE, "c", str(empty)], capture_output=True, text=True)
+    assert r.returncode != 0 and (tmp_path / "empty.txt.et").exists() and (tmp_path / "empty.txt.et").stat().st_size == 0
+
+
+def test_sharded_codec_over_rccl_world_size_1(ctx):
+    """The N > 1 code path of entreepy_amd.sharded (histogram all_gather, offset plan,
+    head shard, boundary all_gather, gather_file) through RCCL on the one GPU we have."""
+    import torch
+    import torch.distributed as dist
+
+    from entreepy_amd import sharded
+    from oracle import oracle as O
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        data = corpus.text_like(3_000_001, 41)
+        text = torch.from_numpy(data).cuda()
+        import entreepy_amd as E
+
+        enc = torch.zeros(E.encode_bound(data.size) + 64, dtype=torch.uint8, device="cuda")
+        codec = sharded.ShardedCodec(ctx, dist.group.WORLD, torch.device("cuda", 0))
+        layout = codec.encode_shard(text, enc)
+        image = codec.gather_file(enc, layout)
+        assert image == O.encode(data)
+        dec = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+        m = codec.decode_shard(enc, layout, dec)
+        torch.cuda.synchronize()
+        assert m == data.size and bool((dec[:m] == text).all())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_large_stream_properties(ctx):
+    """Size-independent checks at a size the oracle does not finish in seconds
+    (1 GiB text-like): decode(encode(x)) == x on the device, the image length equals
+    header + ceil(sum(hist * len) / 8), and encoding the stream as 4 virtual shards at
+    their bit offsets reproduces the single-stream body word for word."""
+    import torch
+
+    import entreepy_amd as E
+
+    n = 1 << 30
+    text = corpus.text_like_torch(n, 0x5EED0004, torch.device("cuda", 0))
+    enc = torch.zeros(E.encode_bound(n) + 64, dtype=torch.uint8, device="cuda")
+    et_len = ctx.encode_device(text, enc)
+    dec = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    m = ctx.decode_device(enc[4:et_len], dec)
+    torch.cuda.synchronize()
+    assert m == n and torch.equal(dec[:n], text)
+    hist = torch.bincount(text.view(torch.uint8).to(torch.int64), minlength=256).cpu().numpy().astype(np.uint64)
+    cb = E.Codebook.from_histogram(hist)
+    header = cb.header(n)
+    assert enc[: len(header)].cpu().numpy().tobytes() == header
+    assert et_len == len(header) + (cb.bits(hist) + 7) // 8
+    # shards
+    whole = enc.clone()  # zero-padded past et_len, so the last word can be compared whole
+    bit = 8 * len(header)
+    h = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for r in range(4):
+        view = text[r * (n // 4) : (r + 1) * (n // 4)]
+        ctx.histogram_device(view, h)
+        out = torch.zeros(view.numel() + 64, dtype=torch.uint8, device="cuda")
+        local = bit % 32
+        end = ctx.encode_body_device(cb, view, out, local)
+        torch.cuda.synchronize()
+        w0, w1 = bit // 32, (bit + end - local + 31) // 32
+        ref = whole[w0 * 4 : w1 * 4].clone()
+        got = out[: (w1 - w0) * 4]
+        # interior words identical; first/last word: the shard's bits are a subset of the stream's
+        assert torch.equal(got[4:-4], ref[4:-4])
+        assert bool(((got[:4] | ref[:4]) == ref[:4]).all()) and bool(((got[-4:] | ref[-4:]) == ref[-4:]).all())
+        bit += end - local
+    assert (bit + 7) // 8 == et_len
