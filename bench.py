@@ -8,7 +8,7 @@ HBM.  Workload at N=1 (BASELINE.json metric): "text-1G", 2^30 bytes of order-0
 samples of res/a_midsummer_nights_dream.txt's byte distribution (no benchmark corpus
 exists offline).  N>1: every rank holds its own 2^30-byte shard of one
 N-GiB stream (weak scaling); the shards share one code table through an RCCL
-all-reduce of the histogram and land at their global bit offsets.
+all-gather of the local histograms and land at their global bit offsets.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -85,11 +85,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # ET_BENCH_DEVICE / ET_DIST_BACKEND exist only to rehearse the N > 1 flow on a
+    # one-GPU box (all ranks on cuda:0 over gloo); the driver's runs use neither.
+    local = int(os.environ.get("ET_BENCH_DEVICE", local))
+    backend = os.environ.get("ET_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = args.bytes
     text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev)
@@ -126,18 +133,20 @@ def main():
     torch.cuda.synchronize()
     assert state["decoded"] == n and torch.equal(dec[:n], text), "round trip is not the identity"
 
-    if world > 1:
-        dist.barrier()
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
+
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -176,7 +185,7 @@ def main():
                             f"(seed 0x5EED0004+rank), one step = encode to .et + decode back, HBM-resident",
                 "bytes_per_gpu": n,
                 "packed_bytes_per_gpu": m_bytes,
-                "sharding": "1 stream" if world == 1 else f"{world} contiguous shards of one stream, RCCL histogram all-reduce + bit-offset all-gather",
+                "sharding": "1 stream" if world == 1 else f"{world} contiguous shards of one stream, RCCL all-gather of the local histograms (sum = global histogram, rows = shard bit counts) + boundary-word all-gather",
                 "value_definition": "text bytes taken through encode+decode per second, all GPUs",
             },
             "encode_GBps": round(world * n / (ms["enc_total"] * 1e-3) / 1e9, 2),
@@ -202,7 +211,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

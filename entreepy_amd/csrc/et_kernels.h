@@ -15,6 +15,9 @@ constexpr uint32_t SUB_BITS = 256;                             // decode: bits p
 constexpr uint32_t DEC_BLOCK_WORDS = BLOCK * SUB_BITS / 32;    // 8 KiB of bitstream per workgroup
 constexpr uint32_t DEC_GUARD_WORDS = 4;                        // words a lane may read past its workgroup's 8 KiB
 // How the decode kernels take their 8 KiB blocks (measured choices; -D overrides for A/B builds):
+#ifndef ET_GRID_MODE
+#define ET_GRID_MODE 1
+#endif
 #ifndef ET_SYNC_CHUNK
 #define ET_SYNC_CHUNK 1
 #endif
@@ -59,7 +62,6 @@ struct DecodeTables {
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist);
-uint32_t hist_rows(uint32_t n_tiles);
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
                       unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
                       unsigned long long *tile_off, uint32_t *out32);

@@ -108,6 +108,9 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t *__restrict__ base, ui
 // serialisation, however skewed the text.  (Per-wavefront private copies would only
 // multiply the LDS footprint: LDS atomics from different wavefronts never overlap in
 // time on the one LDS pipe of a CU.)  32 KiB per workgroup -> 5 workgroups per CU.
+// Measured alternative: two 16-bit counters per word (16 KiB, 8 workgroups per CU) is
+// SLOWER (0.30 vs 0.27 ms per GiB): the ceiling is the ds_add rate itself (~8 LDS
+// cycles per wave-instruction, ~4.9 TB/s chip-wide), not occupancy.
 // Counters are u32 (a tile is at most 64 KiB); tile totals go out as u32,
 // workgroup totals as u64.
 __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
@@ -875,18 +878,31 @@ static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage) 
     return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + sub_w + BLOCK + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 + BLOCK * 4 : 0);
 }
 
-static inline uint32_t hist_grid(uint32_t n_tiles) { return n_tiles < MAX_GRID ? n_tiles : MAX_GRID; }
+// Grid of the tile-striding encode kernels: the workgroups the device holds at once
+// (occupancy query; both kernels use < 64 SGPRs, where the query is exact), so that
+// every workgroup gets within one tile of the same share.  ET_GRID_MODE=0: fixed 2048.
+template <typename K>
+static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
+    uint32_t g = MAX_GRID;
+#if ET_GRID_MODE
+    int dev = 0, cus = 256, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) == hipSuccess && per_cu >= 1)
+        g = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
+    if (g > MAX_GRID) g = MAX_GRID;
+#endif
+    return n_tiles < g ? n_tiles : g;
+}
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist) {
-    const uint32_t grid = hist_grid(n_tiles);
+    const uint32_t grid = n_tiles < MAX_GRID ? n_tiles : MAX_GRID;  // over-subscribed on purpose: an exact-residency grid measured slower for K1
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
     hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist);
     const uint32_t rgrid = grid < 64 ? grid : 64;
     hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
 }
 
-uint32_t hist_rows(uint32_t n_tiles) { return hist_grid(n_tiles); }
 
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
                       unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
@@ -901,13 +917,12 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32) {
-    const uint32_t grid = hist_grid(n_tiles);
     if (max_len > 32)
-        hipLaunchKernelGGL(k_encode_tiles_long, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+        hipLaunchKernelGGL(k_encode_tiles_long, dim3(tile_grid(k_encode_tiles_long, n_tiles)), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
     else if (max_len <= 31)  // a round emits at most 4096 * 31 / 32 + 2 words: fits a 4096-word ring
-        hipLaunchKernelGGL(k_encode_tiles<4096>, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+        hipLaunchKernelGGL(k_encode_tiles<4096>, dim3(tile_grid(k_encode_tiles<4096>, n_tiles)), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
     else
-        hipLaunchKernelGGL(k_encode_tiles<8192>, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+        hipLaunchKernelGGL(k_encode_tiles<8192>, dim3(tile_grid(k_encode_tiles<8192>, n_tiles)), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
 }
 
 // Grid of a chunked decode kernel: one workgroup per chunk, or -- ticketed -- as many

@@ -63,9 +63,12 @@ class ShardedCodec:
         self.device = device
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
+        # collectives run on device tensors with RCCL ("nccl"); with gloo (CPU tests, and
+        # the 2-ranks-on-one-GPU rehearsal of bench.py) they run on host copies
+        self.coll_device = device if (group is None or dist.get_backend(group) == "nccl") else torch.device("cpu")
         self.hist = torch.zeros(256, dtype=torch.int64, device=device)
-        self.all_hists = torch.zeros(self.world * 256, dtype=torch.int64, device=device)
-        self.first_words = torch.zeros(self.world, dtype=torch.int32, device=device)
+        self.all_hists = torch.zeros(self.world * 256, dtype=torch.int64, device=self.coll_device)
+        self.first_words = torch.zeros(self.world, dtype=torch.int32, device=self.coll_device)
         self._hdr_len = {}
 
     # ------------------------------------------------------------------ encode
@@ -90,7 +93,7 @@ class ShardedCodec:
         ctx.histogram_device(text, self.hist)
         hist_ms = ctx.timings()["hist_ms"]
         t_x0 = time.perf_counter()
-        dist.all_gather_into_tensor(self.all_hists, self.hist, group=self.group)
+        dist.all_gather_into_tensor(self.all_hists, self.hist.to(self.coll_device), group=self.group)
         hists = self.all_hists.view(self.world, 256).cpu().numpy().astype(np.uint64)
         t_x1 = time.perf_counter()
         cb, header, starts = plan_shards(hists)
@@ -109,13 +112,13 @@ class ShardedCodec:
         lo, hi = piece_words(starts, r)
         self.first_words.zero_()
         mine = enc[:4].view(torch.int32)
-        dist.all_gather_into_tensor(self.first_words, mine.clone(), group=self.group)
+        dist.all_gather_into_tensor(self.first_words, mine.to(self.coll_device, copy=True), group=self.group)
         if hi > lo:
             last = hi - 1
             for q in range(r + 1, self.world):
                 if starts[q] // 32 == last and starts[q + 1] > starts[q]:
                     w = enc[(last - lo) * 4 : (last - lo) * 4 + 4].view(torch.int32)
-                    w |= self.first_words[q : q + 1]
+                    w |= self.first_words[q : q + 1].to(enc.device)
         if enc.is_cuda:
             torch.cuda.synchronize(self.device)
         t_end = time.perf_counter()
