@@ -29,7 +29,8 @@ struct DevBuf {
 };
 
 constexpr size_t HEADER_STAGE = 8192;  // >= 4631-byte worst-case header, padded
-constexpr size_t SUB_TABLE_BYTES = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) << et::DEC_SUB_BITS_MAX) * sizeof(uint16_t) + 64;  // + slack for 16-byte rounded copies
+constexpr size_t SUB_TABLE_ONLY = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) << et::DEC_SUB_BITS_MAX) * sizeof(uint16_t) + 64;
+constexpr size_t SUB_TABLE_BYTES = SUB_TABLE_ONLY + 256;  // the per-symbol code lengths ride behind the tables  // + slack for 16-byte rounded copies
 
 }  // namespace
 
@@ -56,7 +57,7 @@ struct et_ctx {
     uint8_t *h_header = nullptr;    // HEADER_STAGE
     uint32_t *h_lut = nullptr;      // 1 << DEC_LUT_BITS_MAX
     uint32_t *h_long = nullptr;     // 512
-    uint16_t *h_sub = nullptr;      // DEC_SUB_TABLES_MAX << DEC_SUB_BITS_MAX
+    uint16_t *h_sub = nullptr;      // DEC_SUB_TABLES_MAX << DEC_SUB_BITS_MAX (+ 256 bytes: code length per symbol)
     uint64_t *h_scalar = nullptr;   // 4 (flag / totals)
 
     // link between et_histogram_device and et_encode_body_device
@@ -272,7 +273,7 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_len), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_long), 512 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_sub), SUB_TABLE_BYTES) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 4 * sizeof(uint64_t)) == hipSuccess;
@@ -355,7 +356,7 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->blk_count, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (n_blocks + 1) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->group_sum, (n_blocks / 1024 + 2) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint32_t) << et::DEC_LUT_BITS_MAX));
+    ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
     ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->subt, SUB_TABLE_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
@@ -520,7 +521,8 @@ struct HostDecodeTables {
     uint32_t lut_bits, n_long, sub_bits, n_sub;
 };
 
-void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t *lut, uint32_t *longc, uint16_t *sub, HostDecodeTables *out) {
+void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t *lut, uint32_t *lut_write, uint32_t *longc, uint16_t *sub,
+                         HostDecodeTables *out) {
     const uint32_t k = cb->max_length < lut_bits_max ? (cb->max_length ? cb->max_length : 1) : lut_bits_max;
     const uint32_t n = 1u << k;
     const uint32_t sub_bits = cb->max_length > k ? (cb->max_length - k < et::DEC_SUB_BITS_MAX ? cb->max_length - k : et::DEC_SUB_BITS_MAX) : 0;
@@ -554,18 +556,21 @@ void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t 
         }
     }
     for (uint32_t v = 0; v < n; ++v) {
-        const uint32_t e1 = single[v], len1 = e1 >> 8;
-        uint32_t entry = 0;
-        if (len1) {
-            entry = (e1 & 0xffu) | (len1 << et::LUT_LEN1_SHIFT);
-            const uint32_t rest = (v << len1) & (n - 1);  // the following k - len1 bits, left-aligned in k
-            const uint32_t e2 = single[rest], len2 = e2 >> 8;
-            if (len2 && len1 + len2 <= k)
-                entry |= ((e2 & 0xffu) << 8) | ((len1 + len2) << et::LUT_LEN2_SHIFT) | (1u << et::LUT_TWO_SHIFT);
-        } else if (sub_of[v] >= 0) {
-            entry = static_cast<uint32_t>(sub_of[v]) | (1u << et::LUT_SUB_SHIFT);
+        // greedily take whole codes out of the k-bit index: up to three symbols
+        uint32_t entry = 0, used = 0, cnt = 0, entry_w = 0;
+        while (cnt < et::DEC_SYNC_SYMS) {
+            const uint32_t rest = (v << used) & (n - 1);  // the remaining k - used bits, left-aligned in k
+            const uint32_t e = single[rest], len = e >> 8;
+            if (!len || used + len > k) break;
+            entry |= (e & 0xffu) << (8 * cnt);
+            used += len;
+            ++cnt;
+            if (cnt <= et::DEC_WRITE_SYMS) entry_w = entry | (used << et::LUT_LEN_SHIFT) | (cnt << et::LUT_N_SHIFT);
         }
+        if (cnt) entry |= (used << et::LUT_LEN_SHIFT) | (cnt << et::LUT_N_SHIFT);
+        else if (sub_of[v] >= 0) entry = entry_w = static_cast<uint32_t>(sub_of[v]) | (1u << et::LUT_SUB_SHIFT);
         lut[v] = entry;
+        lut_write[v] = entry_w;
     }
     out->lut_bits = k;
     out->n_long = nl;
@@ -599,7 +604,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->lut, sizeof(uint32_t) << et::DEC_LUT_BITS_MAX));
+    ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
     ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->subt, SUB_TABLE_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
@@ -607,15 +612,19 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     const double t0 = now_ms();
     ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
     HostDecodeTables ht;
-    build_decode_tables(cb, ctx->lut_bits_max, ctx->h_lut, ctx->h_long, ctx->h_sub, &ht);
+    build_decode_tables(cb, ctx->lut_bits_max, ctx->h_lut, ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX), ctx->h_long, ctx->h_sub, &ht);
     const uint32_t lut_bits = ht.lut_bits, n_long = ht.n_long;
     const double t1 = now_ms();
     record(ctx, 0);
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, sizeof(uint32_t) << lut_bits, hipMemcpyHostToDevice, ctx->stream));
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2, hipMemcpyHostToDevice, ctx->stream));
     if (n_long) ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, n_long * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (ht.n_sub) ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, (static_cast<size_t>(ht.n_sub) << ht.sub_bits) * sizeof(uint16_t) + 16, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_ONLY, cb->length, 256);
+    ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, SUB_TABLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
     const et::DecodeTables tb{static_cast<const uint32_t *>(ctx->lut.p), static_cast<const uint32_t *>(ctx->longc.p),
-                              static_cast<const uint16_t *>(ctx->subt.p), lut_bits, n_long, ht.sub_bits, ht.n_sub};
+                              static_cast<const uint16_t *>(ctx->subt.p), static_cast<const uint8_t *>(ctx->subt.p) + SUB_TABLE_ONLY,
+                              lut_bits, n_long, ht.sub_bits, ht.n_sub};
+    et::DecodeTables tb_write = tb;  // same tables, entries cut to DEC_WRITE_SYMS symbols
+    tb_write.lut = tb.lut + (1u << et::DEC_LUT_BITS_MAX);
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
     uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
@@ -653,7 +662,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
 
     // D3
     if (n_out) {
-        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out), flag + 4);
+        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out), flag + 4);
         ET_HIP(hipGetLastError());
     }
     record(ctx, 3);

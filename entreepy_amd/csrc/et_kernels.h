@@ -38,14 +38,16 @@ constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GU
 constexpr uint32_t DEC_SDATA_WORDS = (DEC_STAGED_WORDS + (DEC_STAGED_WORDS >> 5) + 4) & ~3u;  // 1 pad word per 32
 constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: at most 4096 x u32 in LDS
 constexpr uint32_t DEC_LUT_BITS_DEFAULT = 11;                  // measured best on text (K = 10..11 tie, 12 and 9 slower)
-// first-level table entry: byte 0 = first symbol, byte 1 = second symbol,
-// bits 16..19 = length of the first code (0: longer than the table or no code),
-// bits 20..23 = length of both codes, bit 24 = entry holds two symbols
-constexpr uint32_t LUT_LEN1_SHIFT = 16, LUT_LEN2_SHIFT = 20, LUT_TWO_SHIFT = 24;
-// escape entries (first length 0): bit 25 set -> byte 0 is the index of a second-level
-// table of 1 << sub_bits u16 entries ((len << 8) | sym, 0 = not here) indexed by the
-// sub_bits bits that follow the first lut_bits
-constexpr uint32_t LUT_SUB_SHIFT = 25;
+// first-level table entry (u32), indexed by the next lut_bits bits: bytes 0..2 = up to
+// three symbols whose codes all fit in the index, bits 24..27 = total length of those
+// codes, bits 28..29 = how many (0: the first code is longer than the table, or no code
+// starts here).  Escape entries (count 0): bit 30 set -> byte 0 is the index of a
+// second-level table of 1 << sub_bits u16 entries ((len << 8) | sym, 0 = not here)
+// indexed by the sub_bits bits that follow the first lut_bits.
+constexpr uint32_t LUT_LEN_SHIFT = 24, LUT_N_SHIFT = 28, LUT_SUB_SHIFT = 30;
+// symbols per entry: the sync/count sweeps take three; the write kernel two (a third LDS
+// byte store per step costs it more than the saved steps)
+constexpr uint32_t DEC_SYNC_SYMS = 3, DEC_WRITE_SYMS = 2;
 constexpr uint32_t DEC_SUB_BITS_MAX = 8, DEC_SUB_TABLES_MAX = 16;
 constexpr uint32_t DEC_STAGE_BYTES = 16384;                    // LDS staging of decoded symbols
 
@@ -54,6 +56,7 @@ struct DecodeTables {
     const uint32_t *lut;     // [1 << lut_bits] first-level entries (LUT_* above)
     const uint32_t *longc;   // [n_long * 2]: {left-aligned code, (len << 8) | sym} of every code longer than lut_bits
     const uint16_t *sub;     // [n_sub << sub_bits] second-level tables
+    const uint8_t *sym_len;  // [256] code length per symbol (single-symbol steps)
     uint32_t lut_bits;
     uint32_t n_long;
     uint32_t sub_bits;

@@ -470,6 +470,7 @@ struct DecodeSmem {
     uint32_t *sdata;   // DEC_SDATA_WORDS
     uint32_t *lut;     // 1 << lut_bits
     uint16_t *sub;     // n_sub << sub_bits
+    uint8_t *sym_len;  // 256
     uint32_t *exits;   // BLOCK
     uint32_t *scratch; // 8 (scan scratch [0..3], flag [4])
     uint8_t *stage;    // DEC_STAGE_BYTES (write kernel only)
@@ -484,7 +485,8 @@ __device__ __forceinline__ DecodeSmem carve_decode_smem(const DecodeTables &tb) 
     m.sdata = reinterpret_cast<uint32_t *>(dec_smem_raw);
     m.lut = m.sdata + DEC_SDATA_WORDS;
     m.sub = reinterpret_cast<uint16_t *>(m.lut + (1u << tb.lut_bits));
-    m.exits = m.lut + (1u << tb.lut_bits) + sub_words(tb);
+    m.sym_len = reinterpret_cast<uint8_t *>(m.lut + (1u << tb.lut_bits) + sub_words(tb));
+    m.exits = m.lut + (1u << tb.lut_bits) + sub_words(tb) + 64;
     m.scratch = m.exits + BLOCK;
     m.stage = reinterpret_cast<uint8_t *>(m.scratch + 8);
     return m;
@@ -519,6 +521,7 @@ __device__ __forceinline__ void stage_tables(const DecodeSmem &m, const DecodeTa
     for (uint32_t i = threadIdx.x; i < n_lut; i += BLOCK) m.lut[i] = tb.lut[i];
     const uint32_t n_sub_words = sub_words(tb);
     for (uint32_t i = threadIdx.x; i < n_sub_words; i += BLOCK) reinterpret_cast<uint32_t *>(m.sub)[i] = reinterpret_cast<const uint32_t *>(tb.sub)[i];
+    if (threadIdx.x < 64) reinterpret_cast<uint32_t *>(m.sym_len)[threadIdx.x] = reinterpret_cast<const uint32_t *>(tb.sym_len)[threadIdx.x];
 }
 
 __device__ __forceinline__ void prefetch_block(Prefetch &p, const uint32_t *__restrict__ words, uint64_t block, uint64_t n_bytes) {
@@ -549,54 +552,41 @@ struct SubResult {
     uint32_t count;
 };
 
-// One table step: the codeword(s) at the top of `window`.  Returns the bits consumed;
-// n = symbols decoded (0: no codeword there), syms = first symbol in byte 0, second
-// in byte 1 when two.  Only the escape for codes longer than the first-level table
-// (~0.1 % of symbols) branches.
-__device__ __forceinline__ uint32_t table_step(const DecodeSmem &m, const DecodeTables &tb, uint32_t window, bool allow_pair,
-                                               uint32_t &syms, uint32_t &n, bool &two, uint32_t &len1) {
-    const uint32_t e = m.lut[window >> (32 - tb.lut_bits)];
-    len1 = (e >> LUT_LEN1_SHIFT) & 15u;
-    syms = e;
-    two = ((e >> LUT_TWO_SHIFT) & 1u) && allow_pair;
-    uint32_t len = two ? ((e >> LUT_LEN2_SHIFT) & 15u) : len1;
-    n = two ? 2u : 1u;
-    if (len1 == 0) {  // longer than lut_bits, or no codeword at all
-        two = false;
-        uint32_t hit = 0;
-        if ((e >> LUT_SUB_SHIFT) & 1u)
-            hit = m.sub[((e & 0xffu) << tb.sub_bits) | ((window << tb.lut_bits) >> (32 - tb.sub_bits))];
-        if (hit == 0) {  // deeper than both tables (or no table slot left): search the list in global memory
-            for (uint32_t i = 0; i < tb.n_long; ++i) {
-                const uint32_t meta = tb.longc[2 * i + 1], l = meta >> 8;
-                if (((window ^ tb.longc[2 * i]) >> (32 - l)) == 0) {
-                    hit = meta;
-                    break;
-                }
+// Escape of a table step: the first code at the top of `window` is longer than the
+// first-level table (or nothing starts here).  Returns (len << 8) | sym, 0 = no code.
+__device__ __forceinline__ uint32_t long_code(const DecodeSmem &m, const DecodeTables &tb, uint32_t e, uint32_t window) {
+    uint32_t hit = 0;
+    if ((e >> LUT_SUB_SHIFT) & 1u)
+        hit = m.sub[((e & 0xffu) << tb.sub_bits) | ((window << tb.lut_bits) >> (32 - tb.sub_bits))];
+    if (hit == 0) {  // deeper than both tables (or no table slot left): search the list in global memory
+        for (uint32_t i = 0; i < tb.n_long; ++i) {
+            const uint32_t meta = tb.longc[2 * i + 1], l = meta >> 8;
+            if (((window ^ tb.longc[2 * i]) >> (32 - l)) == 0) {
+                hit = meta;
+                break;
             }
         }
-        // no hit: not a codeword (only on a wrong guess or a malformed stream): resynchronise bit by bit
-        len = hit ? (hit >> 8) : 1u;
-        syms = hit & 0xffu;
-        n = hit ? 1u : 0u;
     }
-    return len;
+    return hit;
 }
 
 // Walk the codewords that begin inside subsequence `sub` of the staged block.
 // Positions are bits from the first STAGED bit (DEC_WARMUP_BITS before the block).
-//   WARM: start DEC_WARMUP_BITS before the subsequence and run in (single symbols,
-//         nothing counted); the first codeword boundary at or after the subsequence's
-//         first bit becomes start_rel.  Otherwise start at the given start_rel.
+//   WARM: start DEC_WARMUP_BITS before the subsequence and run in (nothing counted);
+//         the first codeword boundary at or after the subsequence's first bit becomes
+//         start_rel.  Otherwise start at the given start_rel.
 //   `lim` = stream end (same origin), tested only when CHECK_LIM (the block(s) the
 //         stream ends in): a test with a `break` in the hot loop costs ~25 % everywhere.
 // A symbol belongs to the subsequence in which it BEGINS.
 //
-// The loop bodies are written without divergent branches (one scalar unit serves the
-// four SIMDs of a CU, and exec-mask bookkeeping was the first bottleneck): the stream
-// window is the 64-bit pair {r0, r1} read at bit `sh` in [1, 32] with one
-// v_alignbit_b32, r2 holds the word after it, and register rotation, pair selection
-// and the second-symbol store are selects.
+// Every stretch [pos, limit) is walked in two phases: MULTI steps while the whole
+// lut_bits window lies before `limit` -- one lookup yields up to three symbols, all of
+// which therefore begin before `limit` -- then SINGLE steps (first symbol of the entry,
+// its length from sym_len[]) for the last < lut_bits bits.  The loop bodies have no
+// divergent branch except the escape for codes longer than the table (~0.1 % of
+// symbols): one scalar unit serves the four SIMDs of a CU, and exec-mask bookkeeping
+// was the first bottleneck.  The stream window is the 64-bit pair {r0, r1} read at bit
+// `sh` in [1, 32] with one v_alignbit_b32; r2 holds the word after it.
 //
 // WRITE: 0 = count only, 1 = store every symbol at stage[stage_pos + index] (the
 // caller guarantees the whole range is inside the stage), 2 = store only indices in
@@ -607,10 +597,12 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
                                                       uint32_t stage_hi) {
     const uint32_t begin = DEC_WARMUP_BITS + sub * SUB_BITS;
     const uint32_t end = begin + SUB_BITS;
-    const uint32_t end_two = end - tb.lut_bits;  // a pair is usable iff its window starts at or before this bit
-    const uint32_t dummy = DEC_STAGE_BYTES + 16 + threadIdx.x * 4;  // where the second byte of a non-pair goes
+    const uint32_t lut_bits = tb.lut_bits;
+    const uint32_t idx_shift = 32 - lut_bits;
+    const uint32_t dummy = DEC_STAGE_BYTES + 16 + threadIdx.x * 4;  // where the second byte of a 1-symbol step goes
     uint32_t pos = WARM ? begin - DEC_WARMUP_BITS : begin + start_rel;
     uint32_t count = 0;
+    bool off_stream = false;
     SubResult res;
     res.start_rel = start_rel;
 
@@ -635,48 +627,73 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
         r2 = m.sdata[phys(next_word)];            \
     } while (0)
 
+// MULTI: whole-window steps while pos + lut_bits <= limit_ (never past the stream end:
+// the caller clamps limit_).  SINGLE: one symbol per step while pos < limit_.
+#define ET_WALK(limit_, COUNTING)                                                                         \
+    do {                                                                                                  \
+        const uint32_t multi_until_ = (CHECK_LIM && lim < (limit_)) ? lim : (limit_);                     \
+        while (pos + lut_bits <= multi_until_) {                                                          \
+            const uint32_t window_ = __builtin_amdgcn_alignbit(r0, r1, 32 - sh);                          \
+            const uint32_t e_ = m.lut[window_ >> idx_shift];                                              \
+            uint32_t n_ = (e_ >> LUT_N_SHIFT) & 3u, len_ = (e_ >> LUT_LEN_SHIFT) & 15u, syms_ = e_;       \
+            if (n_ == 0) {                                                                                \
+                const uint32_t hit_ = long_code(m, tb, e_, window_);                                      \
+                len_ = hit_ ? (hit_ >> 8) : 1u; /* no code: resynchronise bit by bit */                  \
+                syms_ = hit_ & 0xffu;                                                                     \
+                n_ = hit_ ? 1u : 0u;                                                                      \
+                if (CHECK_LIM && pos + len_ > lim) { off_stream = true; break; }                          \
+            }                                                                                             \
+            if (COUNTING) {                                                                               \
+                if (WRITE == 1) {                                                                         \
+                    const uint32_t o_ = stage_pos + count;                                                \
+                    m.stage[o_] = static_cast<uint8_t>(syms_);                                            \
+                    m.stage[n_ >= 2 ? o_ + 1 : dummy] = static_cast<uint8_t>(syms_ >> 8);                 \
+                    /* the write kernel's table holds at most two symbols per entry (DEC_WRITE_SYMS) */  \
+                } else if (WRITE == 2) {                                                                  \
+                    for (uint32_t j_ = 0; j_ < n_; ++j_) {                                                \
+                        const uint32_t o_ = stage_pos + count + j_;                                       \
+                        if (o_ >= stage_lo && o_ < stage_hi) m.stage[o_ - stage_lo] = static_cast<uint8_t>(syms_ >> (8 * j_)); \
+                    }                                                                                     \
+                }                                                                                         \
+                count += n_;                                                                              \
+            }                                                                                             \
+            ET_ADVANCE(len_);                                                                             \
+        }                                                                                                 \
+        while (!off_stream && pos < (limit_)) {                                                           \
+            const uint32_t window_ = __builtin_amdgcn_alignbit(r0, r1, 32 - sh);                          \
+            const uint32_t e_ = m.lut[window_ >> idx_shift];                                              \
+            uint32_t n_ = (e_ >> LUT_N_SHIFT) & 3u, syms_ = e_ & 0xffu;                                   \
+            uint32_t len_ = m.sym_len[syms_];                                                             \
+            if (n_ == 0) {                                                                                \
+                const uint32_t hit_ = long_code(m, tb, e_, window_);                                      \
+                len_ = hit_ ? (hit_ >> 8) : 1u;                                                           \
+                syms_ = hit_ & 0xffu;                                                                     \
+                n_ = hit_ ? 1u : 0u;                                                                      \
+            } else {                                                                                      \
+                n_ = 1;                                                                                   \
+            }                                                                                             \
+            if (CHECK_LIM && pos + len_ > lim) { off_stream = true; break; }                              \
+            if (COUNTING) {                                                                               \
+                if (WRITE == 1) {                                                                         \
+                    m.stage[n_ ? stage_pos + count : dummy] = static_cast<uint8_t>(syms_);                \
+                } else if (WRITE == 2) {                                                                  \
+                    const uint32_t o_ = stage_pos + count;                                                \
+                    if (n_ && o_ >= stage_lo && o_ < stage_hi) m.stage[o_ - stage_lo] = static_cast<uint8_t>(syms_); \
+                }                                                                                         \
+                count += n_;                                                                              \
+            }                                                                                             \
+            ET_ADVANCE(len_);                                                                             \
+        }                                                                                                 \
+    } while (0)
+
     if (WARM) {
-        while (pos < begin) {
-            uint32_t syms, n, len1;
-            bool two;
-            const uint32_t len = table_step(m, tb, __builtin_amdgcn_alignbit(r0, r1, 32 - sh), false, syms, n, two, len1);
-            if (CHECK_LIM && pos + len > lim) {
-                pos = end;  // the stream ends before this subsequence
-                break;
-            }
-            ET_ADVANCE(len);
-        }
-        res.start_rel = pos < end ? pos - begin : 0u;
+        ET_WALK(begin, false);
+        res.start_rel = off_stream ? 0u : pos - begin;  // the stream may end before this subsequence
     }
-    while (pos < end) {
-        uint32_t syms, n, len1;
-        bool two;
-        // the pair is usable only if the second symbol also begins before `end`
-        uint32_t len = table_step(m, tb, __builtin_amdgcn_alignbit(r0, r1, 32 - sh), pos <= end_two, syms, n, two, len1);
-        if (CHECK_LIM && pos + len > lim) {  // only ever true in the stream's last block
-            if (two && pos + len1 <= lim) {
-                two = false;
-                len = len1;
-                n = 1;
-            } else {
-                pos = end;  // ran off the stream: nothing further begins here
-                break;
-            }
-        }
-        if (WRITE == 1) {
-            const uint32_t o = stage_pos + count;
-            m.stage[o] = static_cast<uint8_t>(syms);
-            m.stage[two ? o + 1 : dummy] = static_cast<uint8_t>(syms >> 8);
-        } else if (WRITE == 2) {
-            const uint32_t o = stage_pos + count;
-            if (n && o >= stage_lo && o < stage_hi) m.stage[o - stage_lo] = static_cast<uint8_t>(syms);
-            if (two && o + 1 >= stage_lo && o + 1 < stage_hi) m.stage[o + 1 - stage_lo] = static_cast<uint8_t>(syms >> 8);
-        }
-        count += n;
-        ET_ADVANCE(len);
-    }
+    if (!off_stream) ET_WALK(end, true);
+#undef ET_WALK
 #undef ET_ADVANCE
-    res.exit_rel = pos - end;
+    res.exit_rel = off_stream ? 0u : pos - end;  // ran off the stream: nothing further begins here
     res.count = count;
     return res;
 }
@@ -875,7 +892,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
 // --------------------------------------------------------------------------------
 static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage) {
     const uint32_t sub_w = (((tb.n_sub << tb.sub_bits) + 7u) & ~7u) / 2;
-    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + sub_w + BLOCK + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 + BLOCK * 4 : 0);
+    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + sub_w + 64 + BLOCK + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 + BLOCK * 4 : 0);
 }
 
 // Grid of the tile-striding encode kernels: the workgroups the device holds at once
