@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 at full size on one MI355X: 16 GiB of uniform random bytes.
+
+All 256 byte values occur, so the reference drops the most frequent symbol (Q1: lossy
+by reference semantics) and the 32-bit length field wraps (Q4).  Encode parity is
+checked against the oracle on a prefix with the full stream's code table, and at full
+size through size-independent properties; decode is exercised on the 255-symbol
+variant (bytes 1..255) just under 4 GiB, where the format is lossless."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import entreepy_amd as E  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+dev = torch.device("cuda", 0)
+ctx = E.Context(0)
+ctx.use_torch_stream()
+
+
+def rand_bytes(n, lo, hi, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        out[s : s + m] = torch.randint(lo, hi, (m,), generator=g, device=dev, dtype=torch.int16).to(torch.uint8)
+    return out
+
+
+def timed(fn, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t)
+    return r, best
+
+
+# ---- encode, 16 GiB, 256 symbols -------------------------------------------------------
+n = 16 << 30
+text = rand_bytes(n, 0, 256, 0x5EED0005)
+enc = torch.zeros(E.encode_bound(n) + 64, dtype=torch.uint8, device=dev)
+ctx.reserve(n)
+et_len, t_enc = timed(lambda: ctx.encode_device(text, enc))
+hist = torch.zeros(256, dtype=torch.int64, device=dev)
+ctx.histogram_device(text, hist)
+h = hist.cpu().numpy().astype(np.uint64)
+assert int(h.sum()) == n and (h > 0).all()
+cb = E.Codebook.from_histogram(h)
+assert cb.raw.n_coded == 255, "Q1: one of 256 symbols is dropped"
+dropped = int(np.where(cb.length == 0)[0][0])
+header = cb.header(n)
+assert enc[: len(header)].cpu().numpy().tobytes() == header
+assert header[5:9] == (n & 0xFFFFFFFF).to_bytes(4, "big") == b"\0\0\0\0", "Q4: length field wraps"
+bits = cb.bits(h)
+assert et_len == len(header) + (bits + 7) // 8
+print(f"encode 16 GiB uniform-256: {n / t_enc / 1e9:.1f} GB/s, {et_len} B out, dropped symbol {dropped}, D byte {header[4]}")
+# oracle parity on a 32 MiB prefix with the FULL stream's code table
+pre = 32 << 20
+want, want_end = O.pack_body(cb.data, cb.length, text[:pre].cpu().numpy(), (len(header) * 8) % 32)
+ctx.histogram_device(text[:pre], hist)
+out = torch.zeros(pre + 64, dtype=torch.uint8, device=dev)
+end = ctx.encode_body_device(cb, text[:pre], out, (len(header) * 8) % 32)
+torch.cuda.synchronize()
+assert end == want_end and out[: len(want)].cpu().numpy().tobytes() == want
+w0 = (len(header) * 8) // 32
+n_words = (want_end // 32) - 1
+assert torch.equal(out[4 : n_words * 4], enc[w0 * 4 + 4 : (w0 + n_words) * 4]), "prefix of the 16 GiB image != oracle-checked prefix encode"
+# four shards at their bit offsets reproduce the single-stream image
+bit = 8 * len(header)
+for r in range(4):
+    view = text[r * (n // 4) : (r + 1) * (n // 4)]
+    ctx.histogram_device(view, hist)
+    sh = torch.zeros(view.numel() + 64, dtype=torch.uint8, device=dev)
+    local = bit % 32
+    e = ctx.encode_body_device(cb, view, sh, local)
+    torch.cuda.synchronize()
+    a, b = bit // 32, (bit + e - local + 31) // 32
+    assert torch.equal(sh[4 : (b - a) * 4 - 4], enc[a * 4 + 4 : b * 4 - 4]), r
+    bit += e - local
+    del sh
+assert (bit + 7) // 8 == et_len
+print("16 GiB: oracle-checked prefix and 4-shard concat agree with the single-stream image")
+del text, enc, out
+torch.cuda.empty_cache()
+
+# ---- encode + decode, 255 symbols, just under 4 GiB ------------------------------------
+n = (4 << 30) - (1 << 20)
+text = rand_bytes(n, 1, 256, 0x5EED0055)
+enc = torch.zeros(E.encode_bound(n) + 64, dtype=torch.uint8, device=dev)
+dec = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+et_len, t_enc = timed(lambda: ctx.encode_device(text, enc))
+m, t_dec = timed(lambda: ctx.decode_device(enc[4:et_len], dec))
+assert m == n and torch.equal(dec[:n], text)
+print(f"uniform-255, {n} B: encode {n / t_enc / 1e9:.1f} GB/s, decode {n / t_dec / 1e9:.1f} GB/s, round trip exact, sync sweeps {ctx.timings()['sync_iters']}")
