@@ -47,6 +47,7 @@ struct et_ctx {
     DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, len_table, group_sum;
     // decode workspaces
     DevBuf sub_state, blk_exit, blk_count, blk_off, lut, longc, subt, flag;
+    DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
     // staging for the host-pointer entry points
     DevBuf io_in, io_out;
 
@@ -292,6 +293,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->len_table, &ctx->group_sum,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->longc, &ctx->subt, &ctx->flag,
+                      &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
                       &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -632,12 +634,38 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
     unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
 
-    // D1: sweep 0 guesses, later sweeps repair; stop after a sweep that changed nothing.
+    // D1: sweep 0 runs in and repairs inside each block; later sweeps repair across
+    // blocks; stop after a sweep that changed nothing.  If sweep 0 reports that blocks
+    // do not synchronise (near-fixed-length codes), switch to the exhaustive path.
     uint32_t iters = 0;
-    et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, sub_state, blk_exit, blk_count, flag, flag + 4);
-    ET_HIP(hipGetLastError());
-    ++iters;
-    for (;;) {
+    // A (nearly) fixed-length code has nothing to re-synchronise on: do not even try.
+    bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
+    if (!exhaustive) {
+        ET_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), ctx->stream));
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, sub_state, blk_exit, blk_count, flag, flag + 4);
+        ET_HIP(hipGetLastError());
+        ++iters;
+        ET_HIP(hipMemcpyAsync(ctx->h_scalar, flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        const uint32_t unconverged = reinterpret_cast<const uint32_t *>(ctx->h_scalar)[1];
+        exhaustive = static_cast<uint64_t>(unconverged) * 64 > n_blocks;
+    }
+    if (exhaustive) {
+        const uint32_t n_starts = cb->max_length;
+        const uint32_t stride = n_starts <= 8 ? 8 : (n_starts <= 16 ? 16 : 32);
+        const size_t n_groups = (static_cast<size_t>(n_blocks) + 255) / 256;
+        ET_TRY(ensure(ctx, ctx->lane_maps, n_subs * stride + 64));
+        ET_TRY(ensure(ctx, ctx->blk_maps, static_cast<size_t>(n_blocks) * 32 + 64));
+        ET_TRY(ensure(ctx, ctx->grp_maps, n_groups * 32 + 64));
+        ET_TRY(ensure(ctx, ctx->blk_in, static_cast<size_t>(n_blocks) + 64));
+        ET_TRY(ensure(ctx, ctx->grp_in, n_groups + 64));
+        et::launch_dec_exhaustive(ctx->stream, words, n_bytes, first_bit, n_subs, tb, n_starts, stride, static_cast<uint8_t *>(ctx->lane_maps.p),
+                                  static_cast<uint8_t *>(ctx->blk_maps.p), static_cast<uint8_t *>(ctx->grp_maps.p),
+                                  static_cast<uint8_t *>(ctx->blk_in.p), static_cast<uint8_t *>(ctx->grp_in.p), sub_state, blk_exit, blk_count);
+        ET_HIP(hipGetLastError());
+        iters += 5;
+    }
+    while (!exhaustive) {
         ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, sub_state, blk_exit, blk_count, flag, flag + 4);
         ET_HIP(hipGetLastError());
@@ -676,6 +704,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm.body_ms = elapsed(ctx, 2, 3);
         ctx->tm.total_ms = elapsed(ctx, 0, 3);
         ctx->tm.sync_iters = iters;
+        ctx->tm.reserved = exhaustive ? 1u : 0u;
     }
     return ET_OK;
 }

@@ -777,7 +777,18 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
         __syncthreads();
 
         const uint32_t lim = block_limit(n_bytes, b);
-        for (;;) {
+        for (uint32_t trip = 0;; ++trip) {
+            if (FIRST && trip == DEC_FIRST_SWEEP_TRIPS) {
+                // Codes that do not self-synchronise (near-fixed-length ones) would crawl
+                // one lane per trip: give up, flag the block, let the host pick the
+                // exhaustive path (k_dec_maps ...).  A start of 0xff makes any later
+                // sweep redo this block.
+                if (tid == 0) {
+                    atomicAdd(changed + 1, 1u);
+                    start = 0xffu;
+                }
+                break;
+            }
             if (need) {
                 SubResult r;
                 if (lim != 0xffffffffu) {  // workgroup-uniform: the stream ends in this block
@@ -811,6 +822,152 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
         if (tid == static_cast<int>(last_live)) blk_exit[b] = exit_rel;
     }
     }
+}
+
+// ---- exhaustive synchronisation -----------------------------------------------------
+// For codes that barely self-synchronise the fixed point above degenerates to one
+// subsequence per trip.  The bounded alternative: every subsequence computes its exit
+// for EVERY possible start offset (n_starts = longest code length of them), which turns
+// "start of i+1 = exit of i" into a composition of small maps; maps compose
+// associatively, so blocks, then groups of 256 blocks, are resolved by short
+// sequential chains over LDS-resident maps instead of sweeps over the stream.
+// Cost: n_starts + 1 walks per subsequence, independent of the data.
+
+// X1: lane maps (stride map_stride bytes per subsequence) and the block's composed map.
+__global__ __launch_bounds__(BLOCK) void k_dec_maps(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit,
+                                                    uint64_t n_subs, DecodeTables tb, uint32_t n_starts, uint32_t map_stride,
+                                                    uint8_t *__restrict__ lane_maps, uint8_t *__restrict__ blk_maps) {
+    const DecodeSmem m = carve_decode_smem(tb);
+    const int tid = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    stage_tables(m, tb);
+    Prefetch pf;
+    prefetch_block(pf, words, b, n_bytes);
+    commit_block(m, pf);
+    __syncthreads();
+
+    const uint64_t sub_g = b * BLOCK + tid;
+    const bool live = sub_g < n_subs;
+    const uint32_t lim = block_limit(n_bytes, b);
+    uint8_t *maps = m.stage;  // [BLOCK][32]
+    for (uint32_t p = 0; p < 32; ++p) {
+        uint32_t e = 0;
+        if (live && (p < n_starts || sub_g == 0)) {
+            const uint32_t st = sub_g == 0 ? first_bit : p;  // the stream's first subsequence has one start, whatever comes in
+            const SubResult r = lim != 0xffffffffu ? walk_subsequence<0, true, false>(m, tb, tid, st, lim, 0, 0, 0)
+                                                   : walk_subsequence<0, false, false>(m, tb, tid, st, lim, 0, 0, 0);
+            e = r.exit_rel;
+        }
+        maps[tid * 32 + p] = static_cast<uint8_t>(e);
+        if (p + 1 >= n_starts && !(b == 0)) break;  // block 0 fills all 32 entries for its first lane
+    }
+    __syncthreads();
+    if (live) {
+        for (uint32_t k = 0; k < map_stride; k += 8)
+            *reinterpret_cast<uint2 *>(lane_maps + sub_g * map_stride + k) = *reinterpret_cast<const uint2 *>(maps + tid * 32 + k);
+    }
+    const uint32_t n_live = static_cast<uint32_t>(n_subs - b * BLOCK >= BLOCK ? BLOCK : n_subs - b * BLOCK);
+    if (tid < 32) {
+        uint32_t sidx = tid;
+        if (static_cast<uint32_t>(tid) < n_starts || b == 0)
+            for (uint32_t i = 0; i < n_live; ++i) sidx = maps[i * 32 + sidx];
+        blk_maps[b * 32 + tid] = static_cast<uint8_t>(sidx);
+    }
+}
+
+// X2: chains over maps.  k_dec_compose composes `count` consecutive 32-byte maps per
+// workgroup (level up); k_dec_chain walks them with a known input and writes the input
+// of every map (level down).  Both stage up to 256 maps in LDS.
+__global__ __launch_bounds__(BLOCK) void k_dec_compose(const uint8_t *__restrict__ maps_in, uint32_t n_maps, uint8_t *__restrict__ maps_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t sm[256 * 32];
+    const uint32_t g = blockIdx.x, first = g * 256;
+    const uint32_t count = n_maps - first < 256 ? n_maps - first : 256;
+    for (uint32_t i = threadIdx.x; i < count * 2; i += BLOCK)
+        reinterpret_cast<uint4 *>(sm)[i] = reinterpret_cast<const uint4 *>(maps_in + static_cast<uint64_t>(first) * 32)[i];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        uint32_t sidx = threadIdx.x;
+        for (uint32_t i = 0; i < count; ++i) sidx = sm[i * 32 + sidx];
+        maps_out[g * 32 + threadIdx.x] = static_cast<uint8_t>(sidx);
+    }
+}
+
+// inputs[i] = input of map i, for the maps [g*256, g*256+256) given the group's input
+// (group_in[g], or first_in when group_in is null: the single top-level workgroup then
+// loops over all groups).
+__global__ __launch_bounds__(BLOCK) void k_dec_chain(const uint8_t *__restrict__ maps, uint32_t n_maps, const uint8_t *__restrict__ group_in,
+                                                     uint32_t first_in, uint8_t *__restrict__ inputs) {
+    __shared__ __attribute__((aligned(16))) uint8_t sm[256 * 32];
+    __shared__ uint8_t s_in[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = group_in ? group_in[blockIdx.x] : first_in;
+    const uint32_t n_groups_here = group_in ? 1 : (n_maps + 255) / 256;
+    for (uint32_t gg = 0; gg < n_groups_here; ++gg) {
+        const uint32_t g = group_in ? blockIdx.x : gg, first = g * 256;
+        const uint32_t count = n_maps - first < 256 ? n_maps - first : 256;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < count * 2; i += BLOCK)
+            reinterpret_cast<uint4 *>(sm)[i] = reinterpret_cast<const uint4 *>(maps + static_cast<uint64_t>(first) * 32)[i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sidx = carry;
+            for (uint32_t i = 0; i < count; ++i) {
+                s_in[i] = static_cast<uint8_t>(sidx);
+                sidx = sm[i * 32 + sidx];
+            }
+            carry = sidx;
+        }
+        __syncthreads();
+        if (threadIdx.x < count) inputs[first + threadIdx.x] = s_in[threadIdx.x];
+    }
+}
+
+// X3: with every block's input start known, resolve the lanes from the stored lane
+// maps, then one counting walk per lane.
+__global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit,
+                                                       uint64_t n_subs, DecodeTables tb, uint32_t map_stride,
+                                                       const uint8_t *__restrict__ lane_maps, const uint8_t *__restrict__ blk_in,
+                                                       uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
+                                                       uint32_t *__restrict__ blk_count) {
+    const DecodeSmem m = carve_decode_smem(tb);
+    const int tid = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    stage_tables(m, tb);
+    Prefetch pf;
+    prefetch_block(pf, words, b, n_bytes);
+    commit_block(m, pf);
+    const uint64_t sub_g = b * BLOCK + tid;
+    const bool live = sub_g < n_subs;
+    uint8_t *maps = m.stage;  // [BLOCK][32]
+    if (live)
+        for (uint32_t k = 0; k < map_stride; k += 8)
+            *reinterpret_cast<uint2 *>(maps + tid * 32 + k) = *reinterpret_cast<const uint2 *>(lane_maps + sub_g * map_stride + k);
+    __syncthreads();
+    const uint32_t n_live = static_cast<uint32_t>(n_subs - b * BLOCK >= BLOCK ? BLOCK : n_subs - b * BLOCK);
+    if (tid == 0) {
+        uint32_t sidx = b == 0 ? first_bit : blk_in[b];
+        for (uint32_t i = 0; i < n_live; ++i) {
+            m.exits[i] = sidx;
+            // the stream's first subsequence has a constant map, of which only the first
+            // map_stride entries were stored; first_bit may lie beyond them
+            sidx = maps[i * 32 + ((b == 0 && i == 0) ? 0u : sidx)];
+        }
+    }
+    __syncthreads();
+    const uint32_t lim = block_limit(n_bytes, b);
+    uint32_t start = 0, exit_rel = 0, count = 0;
+    if (live) {
+        start = m.exits[tid];
+        const SubResult r = lim != 0xffffffffu ? walk_subsequence<0, true, false>(m, tb, tid, start, lim, 0, 0, 0)
+                                               : walk_subsequence<0, false, false>(m, tb, tid, start, lim, 0, 0, 0);
+        exit_rel = r.exit_rel;
+        count = r.count;
+        sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
+    }
+    uint32_t total;
+    block_exclusive_scan(live ? count : 0u, m.scratch, &total);
+    if (tid == 0) blk_count[b] = total;
+    if (tid == static_cast<int>(n_live - 1)) blk_exit[b] = exit_rel;
 }
 
 // D2 (scan of the workgroup symbol counts) is k_scan_local / k_scan_finish above.
@@ -965,6 +1122,23 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
         hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket);
     else
         hipLaunchKernelGGL(k_dec_sync<false>, dim3(decode_grid(k_dec_sync<false>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket);
+}
+
+// Exhaustive synchronisation (see k_dec_maps).  Workspaces: lane_maps n_subs * stride,
+// blk_maps / blk_in per block, grp_maps / grp_in per 256 blocks, top_maps per 65536.
+void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
+                           const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
+                           uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,
+                           uint32_t *blk_count) {
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
+    const uint32_t n_groups = (n_blocks + 255) / 256;
+    const size_t smem = decode_smem_bytes(tb, true);
+    hipLaunchKernelGGL(k_dec_maps, dim3(n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, n_starts, map_stride, lane_maps, blk_maps);
+    hipLaunchKernelGGL(k_dec_compose, dim3(n_groups), dim3(BLOCK), 0, stream, blk_maps, n_blocks, grp_maps);
+    // one workgroup walks all group maps (256 per LDS refill), then every group resolves its blocks
+    hipLaunchKernelGGL(k_dec_chain, dim3(1), dim3(BLOCK), 0, stream, grp_maps, n_groups, static_cast<const uint8_t *>(nullptr), first_bit, grp_in);
+    hipLaunchKernelGGL(k_dec_chain, dim3(n_groups), dim3(BLOCK), 0, stream, blk_maps, n_blocks, grp_in, 0u, blk_in);
+    hipLaunchKernelGGL(k_dec_resolve, dim3(n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, map_stride, lane_maps, blk_in, sub_state, blk_exit, blk_count);
 }
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,

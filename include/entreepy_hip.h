@@ -58,7 +58,7 @@ typedef struct et_timings {
     float sync_ms;      /* decode: self-synchronisation kernels */
     float total_ms;     /* first to last event */
     uint32_t sync_iters;/* decode: synchronisation launches */
-    uint32_t reserved;
+    uint32_t reserved;  /* decode: 1 when the exhaustive synchronisation path ran */
 } et_timings;
 
 typedef struct et_ctx et_ctx;
