@@ -37,6 +37,8 @@ class Timings(ctypes.Structure):
         ("total_ms", ctypes.c_float),
         ("sync_iters", ctypes.c_uint32),
         ("reserved", ctypes.c_uint32),
+        ("sync_first_ms", ctypes.c_float),
+        ("pad_", ctypes.c_uint32),
     ]
 
 

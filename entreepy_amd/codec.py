@@ -181,7 +181,9 @@ class Context:
     def timings(self):
         t = N.Timings()
         _check(N.lib().et_last_timings(self._h, ctypes.byref(t)), self._h)
-        return {k: getattr(t, k) for k, _ in N.Timings._fields_ if k != "reserved"}
+        d = {k: getattr(t, k) for k, _ in N.Timings._fields_ if k not in ("reserved", "pad_")}
+        d["exhaustive_sync"] = bool(t.reserved)
+        return d
 
     # -- whole calls, host memory --------------------------------------------------
     def encode(self, text):

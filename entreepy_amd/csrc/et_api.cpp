@@ -645,6 +645,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, sub_state, blk_exit, blk_count, flag, flag + 4);
         ET_HIP(hipGetLastError());
         ++iters;
+        record(ctx, 5);
         ET_HIP(hipMemcpyAsync(ctx->h_scalar, flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         ET_HIP(hipStreamSynchronize(ctx->stream));
         const uint32_t unconverged = reinterpret_cast<const uint32_t *>(ctx->h_scalar)[1];
@@ -705,6 +706,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm.total_ms = elapsed(ctx, 0, 3);
         ctx->tm.sync_iters = iters;
         ctx->tm.reserved = exhaustive ? 1u : 0u;
+        ctx->tm.sync_first_ms = (iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2)) ? elapsed(ctx, 0, 5) : 0.f;
     }
     return ET_OK;
 }

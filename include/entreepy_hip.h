@@ -59,6 +59,8 @@ typedef struct et_timings {
     float total_ms;     /* first to last event */
     uint32_t sync_iters;/* decode: synchronisation launches */
     uint32_t reserved;  /* decode: 1 when the exhaustive synchronisation path ran */
+    float sync_first_ms;/* decode: the first synchronisation sweep alone (k_dec_sync<first>) */
+    uint32_t pad_;
 } et_timings;
 
 typedef struct et_ctx et_ctx;

@@ -269,3 +269,30 @@ def test_grid_stride_and_multi_round_tiles(ctx):
     want = O.encode(data)
     assert hashlib.sha256(got).digest() == hashlib.sha256(want).digest() and got == want
     assert ctx.decode(got[4:]) == data.tobytes()
+
+
+@pytest.mark.parametrize("k", [3, 4, 5, 16, 17, 64, 100, 200])
+def test_uniform_alphabets_fast_and_exhaustive_sync(ctx, k):
+    """Uniform k-symbol streams: (nearly) fixed-length codes barely self-synchronise, so
+    the decoder takes its exhaustive path (exit map per start + map composition); both
+    paths must agree with the oracle."""
+    n = 200_003
+    data = corpus.uniform(n, 1000 + k, 1, 1 + k)
+    _roundtrip(ctx, data)
+    ctx.enable_timing(True)
+    try:
+        et = ctx.encode(data)
+        assert ctx.decode(et[4:]) == data.tobytes()
+    finally:
+        ctx.enable_timing(False)
+
+
+def test_skewed_then_flat_stream_hits_the_sync_cap(ctx):
+    """A code with spread lengths (fast path chosen by the host) on a stream whose second
+    half uses only the long, equal-length codes: many blocks exceed the local trip cap,
+    and the decoder must still be exact (sweep-0 give-up -> exhaustive path or repairs)."""
+    rng = np.random.default_rng(5)
+    head = corpus.text_like(300_000, 8)
+    rare = np.array([s for s in range(256) if s not in set(head.tolist())][:64], dtype=np.uint8)
+    tail = rare[rng.integers(0, rare.size, size=400_000)]
+    _roundtrip(ctx, np.concatenate([head, tail, head[:1000]]))
