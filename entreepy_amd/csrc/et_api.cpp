@@ -634,22 +634,52 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
     unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
 
-    // D1: sweep 0 runs in and repairs inside each block; later sweeps repair across
-    // blocks; stop after a sweep that changed nothing.  If sweep 0 reports that blocks
-    // do not synchronise (near-fixed-length codes), switch to the exhaustive path.
+    // D1..D3.  Sweep 0 runs in and repairs inside each block; sweeps 1 and 2 repair across
+    // blocks (a sweep that changes nothing ends the search: on text sweep 1 fixes ~0.4 %
+    // of the block boundaries and sweep 2 finds nothing).  Everything up to the write
+    // kernel is enqueued without waiting; the flags and the symbol total are read back
+    // in ONE synchronisation, and only if they say so (blocks that do not synchronise ->
+    // exhaustive path; sweep 2 still changed something -> more sweeps) is the tail redone.
     uint32_t iters = 0;
+    ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
+    unsigned long long *group_sum = static_cast<unsigned long long *>(ctx->group_sum.p);
+    uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 2);  // [0] sweep-1 changed, [1] unconverged blocks, [2] sweep-2 changed
+    const bool can_speculate = cap >= n_symbols;
+    bool wrote = false;
+    auto scan_and_total = [&]() -> int {
+        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off);
+        ET_HIP(hipGetLastError());
+        ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        return ET_OK;
+    };
+    auto write_symbols = [&](uint64_t clamp) -> int {
+        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 4);
+        ET_HIP(hipGetLastError());
+        return ET_OK;
+    };
     // A (nearly) fixed-length code has nothing to re-synchronise on: do not even try.
     bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
+    bool more_sweeps = false;
     if (!exhaustive) {
-        ET_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), ctx->stream));
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, sub_state, blk_exit, blk_count, flag, flag + 4);
-        ET_HIP(hipGetLastError());
-        ++iters;
+        ET_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(uint32_t), ctx->stream));
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4);
         record(ctx, 5);
-        ET_HIP(hipMemcpyAsync(ctx->h_scalar, flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4);
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 2, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag + 2, flag + 4);
+        ET_HIP(hipGetLastError());
+        iters = 3;
+        record(ctx, 1);
+        ET_TRY(scan_and_total());
+        ET_HIP(hipMemcpyAsync(h_flags, flag, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        record(ctx, 2);
+        if (can_speculate) {
+            ET_TRY(write_symbols(n_symbols));
+            wrote = true;
+        }
         ET_HIP(hipStreamSynchronize(ctx->stream));
-        const uint32_t unconverged = reinterpret_cast<const uint32_t *>(ctx->h_scalar)[1];
-        exhaustive = static_cast<uint64_t>(unconverged) * 64 > n_blocks;
+        exhaustive = static_cast<uint64_t>(h_flags[1]) * 64 > n_blocks;
+        more_sweeps = !exhaustive && h_flags[2] != 0;
+        if (exhaustive || more_sweeps) wrote = false;  // the speculative output is void
     }
     if (exhaustive) {
         const uint32_t n_starts = cb->max_length;
@@ -666,34 +696,26 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ET_HIP(hipGetLastError());
         iters += 5;
     }
-    while (!exhaustive) {
+    while (more_sweeps) {
         ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, sub_state, blk_exit, blk_count, flag, flag + 4);
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, 0xffffffffu, sub_state, blk_exit, blk_count, flag, flag + 4);
         ET_HIP(hipGetLastError());
         ++iters;
-        ET_HIP(hipMemcpyAsync(ctx->h_scalar, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipMemcpyAsync(h_flags, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         ET_HIP(hipStreamSynchronize(ctx->stream));
-        if (*reinterpret_cast<const uint32_t *>(ctx->h_scalar) == 0) break;
-        if (iters > n_blocks + 2) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
+        if (h_flags[0] == 0) break;
+        if (iters > n_blocks + 4) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
     }
-    record(ctx, 1);
-
-    // D2
-    ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
-    et::launch_dec_scan(ctx->stream, blk_count, n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), blk_off);
-    ET_HIP(hipGetLastError());
-    ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    record(ctx, 2);
-    ET_HIP(hipStreamSynchronize(ctx->stream));
+    if (exhaustive || more_sweeps) {
+        record(ctx, 1);
+        ET_TRY(scan_and_total());
+        record(ctx, 2);
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+    }
     const uint64_t decodable = ctx->h_scalar[1];
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
-
-    // D3
-    if (n_out) {
-        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, n_out, static_cast<uint8_t *>(d_out), flag + 4);
-        ET_HIP(hipGetLastError());
-    }
+    if (n_out && !wrote) ET_TRY(write_symbols(n_out));
     record(ctx, 3);
     *out_len = static_cast<size_t>(n_out);
     if (ctx->timing) {
@@ -718,15 +740,16 @@ extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t le
     DeviceGuard guard(ctx->device);
     // The header and dictionary (<= 4627 bytes after the 4 stripped ones) are parsed on the host.
     const size_t head = len < HEADER_STAGE ? len : HEADER_STAGE;
-    std::vector<uint8_t> hdr(head);
-    ET_HIP(hipMemcpyAsync(hdr.data(), d_compressed, head, hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));  // the pinned header stage may still feed an earlier encode
+    uint8_t *hdr_data = ctx->h_header;
+    ET_HIP(hipMemcpyAsync(hdr_data, d_compressed, head, hipMemcpyDeviceToHost, ctx->stream));
     ET_HIP(hipStreamSynchronize(ctx->stream));
     et_codebook cb;
     uint64_t n_symbols = 0;
     size_t body_offset = 0;
     // Parsing only needs the dictionary; give the parser the true length when the
     // stream is short so that truncation is detected, else the staged prefix.
-    int rc = et_parse_header(hdr.data(), head, &cb, &n_symbols, &body_offset);
+    int rc = et_parse_header(hdr_data, head, &cb, &n_symbols, &body_offset);
     if (rc != ET_OK) return fail(ctx, rc, "et_parse_header");
     if (body_offset > len) return fail(ctx, ET_ERR_FORMAT, "dictionary runs past the end of the stream");
     return et_decode_body_device(ctx, &cb, static_cast<const uint8_t *>(d_compressed) + body_offset, len - body_offset, 0, n_symbols, d_out, cap, out_len);

@@ -718,10 +718,11 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
                                                     uint64_t n_subs, uint32_t n_blocks, DecodeTables tb,
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
                                                     uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed,
-                                                    uint32_t *__restrict__ ticket) {
+                                                    uint32_t *__restrict__ ticket, uint32_t max_trips) {
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
-    stage_tables(m, tb);
+    bool tables_staged = FIRST;  // repair sweeps copy the tables only if a block needs repair
+    if (FIRST) stage_tables(m, tb);
     Prefetch pf;
     uint32_t round = 0;
     // Blocks are handed out in chunks of SYNC_CHUNK consecutive blocks (tables staged
@@ -771,6 +772,10 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
             __syncthreads();
             if (!*flag) continue;
             if (tid == 0) *changed = 1;
+            if (!tables_staged) {
+                stage_tables(m, tb);
+                tables_staged = true;
+            }
             prefetch_block(pf, words, b, n_bytes);
             commit_block(m, pf);
         }
@@ -778,13 +783,14 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
 
         const uint32_t lim = block_limit(n_bytes, b);
         for (uint32_t trip = 0;; ++trip) {
-            if (FIRST && trip == DEC_FIRST_SWEEP_TRIPS) {
+            if (trip == max_trips) {
                 // Codes that do not self-synchronise (near-fixed-length ones) would crawl
-                // one lane per trip: give up, flag the block, let the host pick the
-                // exhaustive path (k_dec_maps ...).  A start of 0xff makes any later
-                // sweep redo this block.
+                // one lane per trip: give up on this block for now.  The first sweep counts
+                // such blocks so that the host can pick the exhaustive path (k_dec_maps
+                // ...); a start of 0xff makes any later sweep redo the block.
                 if (tid == 0) {
-                    atomicAdd(changed + 1, 1u);
+                    if (FIRST) atomicAdd(changed + 1, 1u);
+                    else *changed = 1;
                     start = 0xffu;
                 }
                 break;
@@ -1112,16 +1118,16 @@ static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticke
 }
 
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
-                     const DecodeTables &tb, uint32_t iter,
+                     const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
     if (SYNC_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (iter == 0)
-        hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket);
+        hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips);
     else
-        hipLaunchKernelGGL(k_dec_sync<false>, dim3(decode_grid(k_dec_sync<false>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket);
+        hipLaunchKernelGGL(k_dec_sync<false>, dim3(decode_grid(k_dec_sync<false>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips);
 }
 
 // Exhaustive synchronisation (see k_dec_maps).  Workspaces: lane_maps n_subs * stride,
