@@ -41,6 +41,7 @@ struct et_ctx {
     bool timing = false;
     uint32_t force_rpt = 0;
     uint32_t lut_bits_max = et::DEC_LUT_BITS_DEFAULT;
+    uint32_t lut_bits_write = et::DEC_LUT_BITS_WRITE;
     std::string err;
 
     // encode workspaces
@@ -266,6 +267,10 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 8 && v <= static_cast<long>(et::DEC_LUT_BITS_MAX)) ctx->lut_bits_max = static_cast<uint32_t>(v);
     }
+    if (const char *env = std::getenv("ET_DEC_LUT_BITS_WRITE")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 8 && v <= static_cast<long>(et::DEC_LUT_BITS_MAX)) ctx->lut_bits_write = static_cast<uint32_t>(v);
+    }
     DeviceGuard guard(device);
     bool ok = guard.ok;
     ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
@@ -275,8 +280,8 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_len), 256 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_long), 512 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_sub), SUB_TABLE_BYTES) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_long), 1024 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_sub), 2 * SUB_TABLE_BYTES) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 4 * sizeof(uint64_t)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
@@ -359,8 +364,8 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->blk_off, (n_blocks + 1) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->group_sum, (n_blocks / 1024 + 2) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
-    ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
-    ET_TRY(ensure(ctx, ctx->subt, SUB_TABLE_BYTES));
+    ET_TRY(ensure(ctx, ctx->longc, 1024 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->subt, 2 * SUB_TABLE_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
     return ET_OK;
 }
@@ -523,7 +528,7 @@ struct HostDecodeTables {
     uint32_t lut_bits, n_long, sub_bits, n_sub;
 };
 
-void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t *lut, uint32_t *lut_write, uint32_t *longc, uint16_t *sub,
+void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t max_syms, uint32_t *lut, uint32_t *longc, uint16_t *sub,
                          HostDecodeTables *out) {
     const uint32_t k = cb->max_length < lut_bits_max ? (cb->max_length ? cb->max_length : 1) : lut_bits_max;
     const uint32_t n = 1u << k;
@@ -559,20 +564,18 @@ void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t 
     }
     for (uint32_t v = 0; v < n; ++v) {
         // greedily take whole codes out of the k-bit index: up to three symbols
-        uint32_t entry = 0, used = 0, cnt = 0, entry_w = 0;
-        while (cnt < et::DEC_SYNC_SYMS) {
+        uint32_t entry = 0, used = 0, cnt = 0;
+        while (cnt < max_syms) {
             const uint32_t rest = (v << used) & (n - 1);  // the remaining k - used bits, left-aligned in k
             const uint32_t e = single[rest], len = e >> 8;
             if (!len || used + len > k) break;
             entry |= (e & 0xffu) << (8 * cnt);
             used += len;
             ++cnt;
-            if (cnt <= et::DEC_WRITE_SYMS) entry_w = entry | (used << et::LUT_LEN_SHIFT) | (cnt << et::LUT_N_SHIFT);
         }
         if (cnt) entry |= (used << et::LUT_LEN_SHIFT) | (cnt << et::LUT_N_SHIFT);
-        else if (sub_of[v] >= 0) entry = entry_w = static_cast<uint32_t>(sub_of[v]) | (1u << et::LUT_SUB_SHIFT);
+        else if (sub_of[v] >= 0) entry = static_cast<uint32_t>(sub_of[v]) | (1u << et::LUT_SUB_SHIFT);
         lut[v] = entry;
-        lut_write[v] = entry_w;
     }
     out->lut_bits = k;
     out->n_long = nl;
@@ -607,26 +610,36 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
-    ET_TRY(ensure(ctx, ctx->longc, 512 * sizeof(uint32_t)));
-    ET_TRY(ensure(ctx, ctx->subt, SUB_TABLE_BYTES));
+    ET_TRY(ensure(ctx, ctx->longc, 1024 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->subt, 2 * SUB_TABLE_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
 
     const double t0 = now_ms();
     ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
-    HostDecodeTables ht;
-    build_decode_tables(cb, ctx->lut_bits_max, ctx->h_lut, ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX), ctx->h_long, ctx->h_sub, &ht);
+    // Two table sets: the sync/count sweeps (index lut_bits_max, DEC_SYNC_SYMS symbols per
+    // entry) and the write kernel (index lut_bits_write, DEC_WRITE_SYMS symbols; its own
+    // second-level tables and long list, since those depend on the index width).
+    HostDecodeTables ht, hw;
+    uint32_t *h_lut_w = ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX);
+    uint32_t *h_long_w = ctx->h_long + 512;
+    uint16_t *h_sub_w = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_BYTES);
+    build_decode_tables(cb, ctx->lut_bits_max, et::DEC_SYNC_SYMS, ctx->h_lut, ctx->h_long, ctx->h_sub, &ht);
+    build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
     const uint32_t lut_bits = ht.lut_bits, n_long = ht.n_long;
     const double t1 = now_ms();
     record(ctx, 0);
     ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2, hipMemcpyHostToDevice, ctx->stream));
-    if (n_long) ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, n_long * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, 1024 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     std::memcpy(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_ONLY, cb->length, 256);
-    ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, SUB_TABLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
+    ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, 2 * SUB_TABLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
     const et::DecodeTables tb{static_cast<const uint32_t *>(ctx->lut.p), static_cast<const uint32_t *>(ctx->longc.p),
                               static_cast<const uint16_t *>(ctx->subt.p), static_cast<const uint8_t *>(ctx->subt.p) + SUB_TABLE_ONLY,
                               lut_bits, n_long, ht.sub_bits, ht.n_sub};
-    et::DecodeTables tb_write = tb;  // same tables, entries cut to DEC_WRITE_SYMS symbols
-    tb_write.lut = tb.lut + (1u << et::DEC_LUT_BITS_MAX);
+    const et::DecodeTables tb_write{tb.lut + (1u << et::DEC_LUT_BITS_MAX), tb.longc + 512,
+                                    reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(ctx->subt.p) + SUB_TABLE_BYTES),
+                                    static_cast<const uint8_t *>(ctx->subt.p) + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
+                                    hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub};
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
     uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);

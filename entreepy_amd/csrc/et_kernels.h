@@ -39,6 +39,7 @@ constexpr uint32_t DEC_WARMUP_BITS = DEC_FRONT_WORDS * 32;     // run-in before 
 constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GUARD_WORDS;
 constexpr uint32_t DEC_SDATA_WORDS = (DEC_STAGED_WORDS + (DEC_STAGED_WORDS >> 5) + 4) & ~3u;  // 1 pad word per 32
 constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: at most 4096 x u32 in LDS
+constexpr uint32_t DEC_LUT_BITS_WRITE = 10;                    // write kernel: 4 KiB table keeps it under 32 KiB of LDS (5 workgroups per CU)
 constexpr uint32_t DEC_LUT_BITS_DEFAULT = 11;                  // measured best on text (K = 10..11 tie, 12 and 9 slower)
 // first-level table entry (u32), indexed by the next lut_bits bits: bytes 0..2 = up to
 // three symbols whose codes all fit in the index, bits 24..27 = total length of those

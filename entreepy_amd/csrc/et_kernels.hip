@@ -480,6 +480,9 @@ extern __shared__ __attribute__((aligned(16))) uint8_t dec_smem_raw[];
 
 __device__ __forceinline__ uint32_t sub_words(const DecodeTables &tb) { return (((tb.n_sub << tb.sub_bits) + 7u) & ~7u) / 2; }
 
+// WITH_EXITS: the sync kernels exchange exits through LDS; the write kernel does not and
+// must stay under 32 KiB (5 workgroups per CU).
+template <bool WITH_EXITS = true>
 __device__ __forceinline__ DecodeSmem carve_decode_smem(const DecodeTables &tb) {
     DecodeSmem m;
     m.sdata = reinterpret_cast<uint32_t *>(dec_smem_raw);
@@ -487,7 +490,7 @@ __device__ __forceinline__ DecodeSmem carve_decode_smem(const DecodeTables &tb) 
     m.sub = reinterpret_cast<uint16_t *>(m.lut + (1u << tb.lut_bits));
     m.sym_len = reinterpret_cast<uint8_t *>(m.lut + (1u << tb.lut_bits) + sub_words(tb));
     m.exits = m.lut + (1u << tb.lut_bits) + sub_words(tb) + 64;
-    m.scratch = m.exits + BLOCK;
+    m.scratch = m.exits + (WITH_EXITS ? BLOCK : 0);
     m.stage = reinterpret_cast<uint8_t *>(m.scratch + 8);
     return m;
 }
@@ -599,7 +602,6 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
     const uint32_t end = begin + SUB_BITS;
     const uint32_t lut_bits = tb.lut_bits;
     const uint32_t idx_shift = 32 - lut_bits;
-    const uint32_t dummy = DEC_STAGE_BYTES + 16 + threadIdx.x * 4;  // where the second byte of a 1-symbol step goes
     uint32_t pos = WARM ? begin - DEC_WARMUP_BITS : begin + start_rel;
     uint32_t count = 0;
     bool off_stream = false;
@@ -646,8 +648,10 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
             if (COUNTING) {                                                                               \
                 if (WRITE == 1) {                                                                         \
                     const uint32_t o_ = stage_pos + count;                                                \
+                    /* second byte first, at o + (n == 2); then the first symbol at o: a one-symbol */   \
+                    /* step stores twice to the same byte and the later store (the symbol) wins     */   \
+                    m.stage[o_ + (n_ >> 1)] = static_cast<uint8_t>(syms_ >> 8);                           \
                     m.stage[o_] = static_cast<uint8_t>(syms_);                                            \
-                    m.stage[n_ >= 2 ? o_ + 1 : dummy] = static_cast<uint8_t>(syms_ >> 8);                 \
                     /* the write kernel's table holds at most two symbols per entry (DEC_WRITE_SYMS) */  \
                 } else if (WRITE == 2) {                                                                  \
                     for (uint32_t j_ = 0; j_ < n_; ++j_) {                                                \
@@ -675,7 +679,7 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
             if (CHECK_LIM && pos + len_ > lim) { off_stream = true; break; }                              \
             if (COUNTING) {                                                                               \
                 if (WRITE == 1) {                                                                         \
-                    m.stage[n_ ? stage_pos + count : dummy] = static_cast<uint8_t>(syms_);                \
+                    if (n_) m.stage[stage_pos + count] = static_cast<uint8_t>(syms_);                     \
                 } else if (WRITE == 2) {                                                                  \
                     const uint32_t o_ = stage_pos + count;                                                \
                     if (n_ && o_ >= stage_lo && o_ < stage_hi) m.stage[o_ - stage_lo] = static_cast<uint8_t>(syms_); \
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
                                                      uint32_t n_blocks, DecodeTables tb, const uint32_t *__restrict__ sub_state,
                                                      const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ ticket) {
-    const DecodeSmem m = carve_decode_smem(tb);
+    const DecodeSmem m = carve_decode_smem<false>(tb);
     const int tid = threadIdx.x;
     stage_tables(m, tb);
     Prefetch pf;
@@ -1053,9 +1057,9 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
 // --------------------------------------------------------------------------------
 // launch wrappers (plain C++ callable; everything is enqueued on `stream`)
 // --------------------------------------------------------------------------------
-static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage) {
+static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage, bool with_exits = true) {
     const uint32_t sub_w = (((tb.n_sub << tb.sub_bits) + 7u) & ~7u) / 2;
-    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + sub_w + 64 + BLOCK + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 + BLOCK * 4 : 0);
+    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + sub_w + 64 + (with_exits ? BLOCK : 0) + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 : 0);
 }
 
 // Grid of the tile-striding encode kernels: the workgroups the device holds at once
@@ -1159,7 +1163,7 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
-    const size_t smem = decode_smem_bytes(tb, true);
+    const size_t smem = decode_smem_bytes(tb, true, false);
     if (WRITE_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket);
 }
