@@ -296,3 +296,56 @@ def test_skewed_then_flat_stream_hits_the_sync_cap(ctx):
     rare = np.array([s for s in range(256) if s not in set(head.tolist())][:64], dtype=np.uint8)
     tail = rare[rng.integers(0, rare.size, size=400_000)]
     _roundtrip(ctx, np.concatenate([head, tail, head[:1000]]))
+
+
+def test_property_random_streams(ctx):
+    """hypothesis: arbitrary byte strings -- GPU encode == oracle encode, GPU decode ==
+    oracle's intended decode (== input whenever the format is lossless)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    O = _oracle()
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.one_of(
+        st.binary(min_size=1, max_size=3000),
+        st.lists(st.sampled_from([0, 1, 2, 3, 255]), min_size=1, max_size=5000).map(bytes),
+        st.tuples(st.integers(1, 255), st.integers(1, 70000)).map(lambda t: bytes([t[0]]) * t[1]),
+    ))
+    def check(data):
+        want = O.encode(data)
+        got = ctx.encode(data)
+        assert got == want
+        assert ctx.decode(got[4:]) == O.decode(want[4:])
+
+    check()
+
+
+def test_decode_rejects_malformed_streams(ctx):
+    """The reference validates nothing (main.zig:199 TODO); the library must fail with a
+    status, never crash or hang, on truncated or corrupted inputs."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    text = corpus.text_like(50_000, 3)
+    et = O.encode(text)
+    good = et[4:]
+    for cut in (0, 3, 4, 8, 40):
+        with pytest.raises(E.EntreepyError):
+            ctx.decode(good[:cut])
+    # body truncated: decodes what is there, fewer symbols than declared
+    _, n, off = E.parse_header(good)
+    part = ctx.decode(good[: off + 1000])
+    assert 0 < len(part) < n and text.tobytes().startswith(part)
+    # dictionary corrupted so that two codes collide
+    bad = bytearray(good)
+    bad[7] ^= 0xFF
+    try:
+        out = ctx.decode(bytes(bad))
+        assert len(out) <= n  # a still-valid (different) code table: any bounded output is acceptable
+    except E.EntreepyError:
+        pass
+    # random garbage after a valid header must terminate
+    rng = np.random.default_rng(1)
+    junk = good[:off] + rng.integers(0, 256, size=20000, dtype=np.uint8).tobytes()
+    assert len(ctx.decode(junk)) <= n
