@@ -42,6 +42,16 @@ class Timings(ctypes.Structure):
     ]
 
 
+class RangeInfo(ctypes.Structure):
+    _fields_ = [
+        ("start_bit", ctypes.c_uint32),
+        ("exit_bit", ctypes.c_uint32),
+        ("n_symbols", ctypes.c_uint64),
+        ("sweeps", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+    ]
+
+
 _vp, _sz, _u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64
 _szp = ctypes.POINTER(ctypes.c_size_t)
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -74,6 +84,8 @@ SIGNATURES = {
     "et_encode_body_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _vp, _sz, _u64, _u64p]),
     "et_encode_head_shard_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _vp, _sz, _vp, _sz, _u64p]),
     "et_parse_header": (ctypes.c_int, [_vp, _sz, _cbp, _u64p, _szp]),
+    "et_decode_range_sync": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _sz, ctypes.c_int, ctypes.c_int32, ctypes.POINTER(RangeInfo)]),
+    "et_decode_range_write": (ctypes.c_int, [_vp, _u64, _vp, _sz, _szp]),
     "et_decode_body_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, ctypes.c_uint32, _u64, _vp, _sz, _szp]),
 }
 

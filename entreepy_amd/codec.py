@@ -242,6 +242,24 @@ class Context:
         return n.value
 
 
+    def decode_range_sync(self, codebook, stream, begin, end, in_start_bit=-1):
+        """One rank's part of a cold multi-GPU decode: synchronise the codewords that begin
+        in stream[begin:end] (uint8 device tensor of the body from its 4-byte aligned base;
+        begin a multiple of 8192, end too unless it is the stream's end).  Call again with
+        the predecessor's exit as in_start_bit to repair.  -> dict(start_bit, exit_bit,
+        n_symbols, sweeps)."""
+        info = N.RangeInfo()
+        tail = stream.numel() - end
+        _check(N.lib().et_decode_range_sync(self._h, ctypes.byref(codebook.raw), stream.data_ptr() + begin, end - begin, tail,
+                                            int(begin >= 16), int(in_start_bit), ctypes.byref(info)), self._h)
+        return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps}
+
+    def decode_range_write(self, max_symbols, out):
+        n = ctypes.c_size_t(0)
+        _check(N.lib().et_decode_range_write(self._h, int(max_symbols), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
+        return n.value
+
+
 _default_ctx = {}
 
 

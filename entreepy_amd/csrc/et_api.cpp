@@ -72,6 +72,15 @@ struct et_ctx {
     et_timings tm = {};
     et_codebook last_cb = {};
     bool have_cb = false;
+
+    // et_decode_range_sync -> et_decode_range_write
+    struct {
+        bool valid = false;
+        const uint32_t *words = nullptr;
+        uint64_t n_bytes = 0, n_subs = 0, total = 0;
+        uint32_t n_blocks = 0, flags = 0;
+        et::DecodeTables tb = {}, tb_write = {};
+    } range;
 };
 
 namespace {
@@ -583,6 +592,36 @@ void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t 
     out->n_sub = n_sub;
 }
 
+// Build both table sets on the host and upload them: the sync/count sweeps (index
+// lut_bits_max, DEC_SYNC_SYMS symbols per entry) and the write kernel (index lut_bits_write,
+// DEC_WRITE_SYMS symbols; its own second-level tables and long list, since those depend on
+// the index width).
+int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *tb_out, et::DecodeTables *tb_write_out) {
+    ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
+    ET_TRY(ensure(ctx, ctx->longc, 1024 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->subt, 2 * SUB_TABLE_BYTES));
+    ET_TRY(ensure(ctx, ctx->flag, 64));
+    ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
+    HostDecodeTables ht, hw;
+    uint32_t *h_lut_w = ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX);
+    uint32_t *h_long_w = ctx->h_long + 512;
+    uint16_t *h_sub_w = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_BYTES);
+    build_decode_tables(cb, ctx->lut_bits_max, et::DEC_SYNC_SYMS, ctx->h_lut, ctx->h_long, ctx->h_sub, &ht);
+    build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
+    std::memcpy(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_ONLY, cb->length, 256);
+    std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2, hipMemcpyHostToDevice, ctx->stream));
+    ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, 1024 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, 2 * SUB_TABLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t *subt = static_cast<const uint8_t *>(ctx->subt.p);
+    *tb_out = et::DecodeTables{static_cast<const uint32_t *>(ctx->lut.p), static_cast<const uint32_t *>(ctx->longc.p),
+                               reinterpret_cast<const uint16_t *>(subt), subt + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits, ht.n_sub};
+    *tb_write_out = et::DecodeTables{tb_out->lut + (1u << et::DEC_LUT_BITS_MAX), tb_out->longc + 512,
+                                     reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES), subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
+                                     hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub};
+    return ET_OK;
+}
+
 }  // namespace
 
 extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body, size_t body_bytes, uint32_t start_bit,
@@ -609,37 +648,13 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
-    ET_TRY(ensure(ctx, ctx->longc, 1024 * sizeof(uint32_t)));
-    ET_TRY(ensure(ctx, ctx->subt, 2 * SUB_TABLE_BYTES));
-    ET_TRY(ensure(ctx, ctx->flag, 64));
 
+    ctx->range.valid = false;  // shares the workspaces
     const double t0 = now_ms();
-    ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
-    // Two table sets: the sync/count sweeps (index lut_bits_max, DEC_SYNC_SYMS symbols per
-    // entry) and the write kernel (index lut_bits_write, DEC_WRITE_SYMS symbols; its own
-    // second-level tables and long list, since those depend on the index width).
-    HostDecodeTables ht, hw;
-    uint32_t *h_lut_w = ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX);
-    uint32_t *h_long_w = ctx->h_long + 512;
-    uint16_t *h_sub_w = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_BYTES);
-    build_decode_tables(cb, ctx->lut_bits_max, et::DEC_SYNC_SYMS, ctx->h_lut, ctx->h_long, ctx->h_sub, &ht);
-    build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
-    const uint32_t lut_bits = ht.lut_bits, n_long = ht.n_long;
+    et::DecodeTables tb, tb_write;
+    ET_TRY(prepare_decode_tables(ctx, cb, &tb, &tb_write));
     const double t1 = now_ms();
     record(ctx, 0);
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2, hipMemcpyHostToDevice, ctx->stream));
-    ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, 1024 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    std::memcpy(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_ONLY, cb->length, 256);
-    std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
-    ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, 2 * SUB_TABLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
-    const et::DecodeTables tb{static_cast<const uint32_t *>(ctx->lut.p), static_cast<const uint32_t *>(ctx->longc.p),
-                              static_cast<const uint16_t *>(ctx->subt.p), static_cast<const uint8_t *>(ctx->subt.p) + SUB_TABLE_ONLY,
-                              lut_bits, n_long, ht.sub_bits, ht.n_sub};
-    const et::DecodeTables tb_write{tb.lut + (1u << et::DEC_LUT_BITS_MAX), tb.longc + 512,
-                                    reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(ctx->subt.p) + SUB_TABLE_BYTES),
-                                    static_cast<const uint8_t *>(ctx->subt.p) + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
-                                    hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub};
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
     uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
@@ -743,6 +758,100 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm.reserved = exhaustive ? 1u : 0u;
         ctx->tm.sync_first_ms = (iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2)) ? elapsed(ctx, 0, 5) : 0.f;
     }
+    return ET_OK;
+}
+
+extern "C" int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const void *d_range, size_t range_bytes, size_t tail_bytes,
+                                    int has_front, int32_t in_start_bit, et_range_info *info) {
+    if (!ctx || !cb || !d_range || !info || range_bytes == 0) return ET_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_range) & 3) return fail(ctx, ET_ERR_ARG, "d_range must be 4-byte aligned");
+    if (tail_bytes && (range_bytes % (et::DEC_BLOCK_WORDS * 4) || tail_bytes < 16)) return fail(ctx, ET_ERR_ARG, "an inner range is a multiple of 8192 bytes with >= 16 bytes after it");
+    if (in_start_bit >= 32) return fail(ctx, ET_ERR_ARG, "in_start_bit must be < 32");
+    if (in_start_bit < 0 && !has_front) return fail(ctx, ET_ERR_ARG, "an unknown start needs the 16 bytes in front of the range");
+    if (cb->max_length > 32) return fail(ctx, ET_ERR_UNSUPPORTED, "code length > 32");
+    if (cb->n_coded == 0) return fail(ctx, ET_ERR_ARG, "empty code table");
+    DeviceGuard guard(ctx->device);
+    const uint32_t *words = static_cast<const uint32_t *>(d_range);
+    const uint64_t n_bytes = static_cast<uint64_t>(range_bytes) + tail_bytes;
+    const uint64_t n_subs = (static_cast<uint64_t>(range_bytes) * 8 + et::SUB_BITS - 1) / et::SUB_BITS;
+    const uint64_t n_blocks64 = (n_subs + et::BLOCK - 1) / et::BLOCK;
+    if (n_blocks64 > 0x7fffffffull) return fail(ctx, ET_ERR_ARG, "range too large");
+    const uint32_t n_blocks = static_cast<uint32_t>(n_blocks64);
+    auto &rs = ctx->range;
+    const bool repair = rs.valid && rs.words == words && rs.n_subs == n_subs && in_start_bit >= 0;
+    uint32_t sweeps = 0;
+    if (!repair) {
+        rs.valid = false;
+        ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));
+        ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+        ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+        ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
+        ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
+        ET_TRY(prepare_decode_tables(ctx, cb, &rs.tb, &rs.tb_write));
+        rs.words = words;
+        rs.n_bytes = n_bytes;
+        rs.n_subs = n_subs;
+        rs.n_blocks = n_blocks;
+    }
+    rs.flags = (in_start_bit >= 0 ? et::DEC_HAVE_START : 0u) | (has_front ? et::DEC_FRONT_OK : 0u);
+    const uint32_t first_bit = in_start_bit >= 0 ? static_cast<uint32_t>(in_start_bit) : 0u;
+    uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
+    uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
+    uint32_t *blk_count = static_cast<uint32_t *>(ctx->blk_count.p);
+    uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
+    unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
+    uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 2);
+    if (!repair) {
+        // Sweep 0 (run-in, local repair with a trip cap); codes that do not synchronise take
+        // many capped sweeps here -- the exhaustive path is single-GPU only for now.
+        ET_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(uint32_t), ctx->stream));
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, rs.tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag,
+                            flag + 4, rs.flags);
+        ET_HIP(hipGetLastError());
+        ++sweeps;
+    }
+    for (;;) {
+        ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, rs.tb, 1 + sweeps, 0xffffffffu, sub_state, blk_exit, blk_count, flag, flag + 4,
+                            rs.flags);
+        ET_HIP(hipGetLastError());
+        ++sweeps;
+        ET_HIP(hipMemcpyAsync(h_flags, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_flags[0] == 0) break;
+        if (sweeps > n_blocks + 4) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
+    }
+    et::launch_dec_scan(ctx->stream, blk_count, n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), blk_off);
+    ET_HIP(hipGetLastError());
+    ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipMemcpyAsync(h_flags, sub_state, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipMemcpyAsync(h_flags + 1, blk_exit + (n_blocks - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    rs.total = ctx->h_scalar[1];
+    rs.valid = true;
+    info->start_bit = h_flags[0] & 0xffu;
+    info->exit_bit = h_flags[1];
+    info->n_symbols = rs.total;
+    info->sweeps = sweeps;
+    info->reserved = 0;
+    return ET_OK;
+}
+
+extern "C" int et_decode_range_write(et_ctx *ctx, uint64_t max_symbols, void *d_out, size_t cap, size_t *out_len) {
+    if (!ctx || !out_len) return ET_ERR_ARG;
+    *out_len = 0;
+    auto &rs = ctx->range;
+    if (!rs.valid) return fail(ctx, ET_ERR_ARG, "et_decode_range_write needs et_decode_range_sync first");
+    const uint64_t n_out = rs.total < max_symbols ? rs.total : max_symbols;
+    if (n_out == 0) return ET_OK;
+    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15)) return fail(ctx, ET_ERR_ARG, "d_out must be 16-byte aligned");
+    if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
+    DeviceGuard guard(ctx->device);
+    et::launch_dec_write(ctx->stream, rs.words, rs.n_bytes, rs.n_subs, rs.tb_write, static_cast<const uint32_t *>(ctx->sub_state.p),
+                         static_cast<const unsigned long long *>(ctx->blk_off.p), n_out, static_cast<uint8_t *>(d_out),
+                         static_cast<uint32_t *>(ctx->flag.p) + 4);
+    ET_HIP(hipGetLastError());
+    *out_len = static_cast<size_t>(n_out);
     return ET_OK;
 }
 

@@ -34,6 +34,7 @@ constexpr uint32_t SYNC_CHUNK = ET_SYNC_CHUNK, WRITE_CHUNK = ET_WRITE_CHUNK;  //
 constexpr bool SYNC_TICKET = ET_SYNC_TICKET, WRITE_TICKET = ET_WRITE_TICKET;  // chunks by ticket counter vs one per workgroup
 constexpr uint32_t DEC_FIRST_SWEEP_TRIPS = 6;                   // local fixed-point trips before a block is declared non-synchronising
 constexpr uint32_t DEC_REPAIR_SWEEP_TRIPS = 8;                  // same cap for the two speculatively enqueued repair sweeps
+constexpr uint32_t DEC_HAVE_START = 1, DEC_FRONT_OK = 2;       // k_dec_sync flags (ranges of a stream split over GPUs)
 constexpr uint32_t DEC_FRONT_WORDS = 4;                        // words staged BEFORE the workgroup's 8 KiB (warm-up run-in)
 constexpr uint32_t DEC_WARMUP_BITS = DEC_FRONT_WORDS * 32;     // run-in before each subsequence in the first sync sweep
 constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GUARD_WORDS;
@@ -75,7 +76,8 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32);
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
-                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket);
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket,
+                     uint32_t flags = DEC_HAVE_START);
 void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                            const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
                            uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,

@@ -527,16 +527,21 @@ __device__ __forceinline__ void stage_tables(const DecodeSmem &m, const DecodeTa
     if (threadIdx.x < 64) reinterpret_cast<uint32_t *>(m.sym_len)[threadIdx.x] = reinterpret_cast<const uint32_t *>(tb.sym_len)[threadIdx.x];
 }
 
-__device__ __forceinline__ void prefetch_block(Prefetch &p, const uint32_t *__restrict__ words, uint64_t block, uint64_t n_bytes) {
+// front_ok: the DEC_FRONT_WORDS words BEFORE `words` are readable stream bytes (a rank's
+// range of a stream decoded on several GPUs); otherwise they read as zero.
+__device__ __forceinline__ void prefetch_block(Prefetch &p, const uint32_t *__restrict__ words, uint64_t block, uint64_t n_bytes,
+                                               bool front_ok = false) {
     const uint64_t first_word = block * DEC_BLOCK_WORDS;
     // workgroup-uniform: every staged word lies wholly inside the stream
-    const bool interior = first_word >= DEC_FRONT_WORDS && (first_word - DEC_FRONT_WORDS + DEC_STAGED_WORDS) * 4 <= n_bytes;
+    const bool interior = (first_word >= DEC_FRONT_WORDS || front_ok) && (first_word + DEC_STAGED_WORDS - DEC_FRONT_WORDS) * 4 <= n_bytes;
 #pragma unroll
     for (int j = 0; j < DEC_WORDS_PER_THREAD; ++j) {
         const uint32_t i = j * BLOCK + threadIdx.x;
         if (i < DEC_STAGED_WORDS) {
-            if (interior) p.w[j] = __builtin_bswap32(words[first_word - DEC_FRONT_WORDS + i]);
-            else p.w[j] = (first_word + i < DEC_FRONT_WORDS) ? 0u : load_be32_guarded(words, first_word + i - DEC_FRONT_WORDS, n_bytes);
+            const long long w = static_cast<long long>(first_word + i) - DEC_FRONT_WORDS;  // negative: before `words`
+            if (interior) p.w[j] = __builtin_bswap32(words[w]);
+            else if (w < 0) p.w[j] = front_ok ? __builtin_bswap32(words[w]) : 0u;
+            else p.w[j] = load_be32_guarded(words, static_cast<uint64_t>(w), n_bytes);
         }
     }
 }
@@ -722,7 +727,11 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
                                                     uint64_t n_subs, uint32_t n_blocks, DecodeTables tb,
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
                                                     uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed,
-                                                    uint32_t *__restrict__ ticket, uint32_t max_trips) {
+                                                    uint32_t *__restrict__ ticket, uint32_t max_trips, uint32_t flags) {
+    // flags (DEC_HAVE_START: first_bit is the exact start of subsequence 0; DEC_FRONT_OK:
+    // the words before `words` belong to the stream) differ from {1, 0} only for a rank's
+    // range of a stream decoded on several GPUs.
+    const bool have_start = flags & DEC_HAVE_START, front_ok = flags & DEC_FRONT_OK;
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
     bool tables_staged = FIRST;  // repair sweeps copy the tables only if a block needs repair
@@ -748,18 +757,18 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
         }
         if (b0 >= n_blocks) break;
         const uint64_t b1 = b0 + SYNC_CHUNK < n_blocks ? b0 + SYNC_CHUNK : n_blocks;
-        if (FIRST) prefetch_block(pf, words, b0, n_bytes);
+        if (FIRST) prefetch_block(pf, words, b0, n_bytes, front_ok);
     for (uint64_t b = b0; b < b1; ++b, ++round) {
         const uint64_t sub_g = b * BLOCK + tid;
         const bool live = sub_g < n_subs;
-        uint32_t start, exit_rel = 0, count = 0;
+        uint32_t start, exit_rel = 0, count = 0, first_cand = 0;
         bool need, warm = false;
         if (FIRST) {
             start = first_bit;  // exact for the stream's first subsequence; every other one runs in
-            warm = sub_g != 0;
+            warm = sub_g != 0 || !have_start;
             need = live;
             commit_block(m, pf);
-            if (b + 1 < b1) prefetch_block(pf, words, b + 1, n_bytes);
+            if (b + 1 < b1) prefetch_block(pf, words, b + 1, n_bytes, front_ok);
         } else {
             const uint32_t st = live ? sub_state[sub_g] : 0u;
             start = st & 0xffu;
@@ -768,9 +777,11 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
             need = false;
             uint32_t *flag = m.scratch + 4 + (round & 1);
             if (tid == 0) {
-                const uint32_t in = (b == 0) ? first_bit : blk_exit[b - 1];
-                need = in != start;
-                start = in;
+                const uint32_t in = (b == 0) ? (have_start ? first_bit : start) : blk_exit[b - 1];
+                // a range whose start is still unknown and whose first block gave up: run in again
+                warm = b == 0 && !have_start && start == 0xffu;
+                need = warm || in != start;
+                first_cand = in;
                 *flag = need;
             }
             __syncthreads();
@@ -780,12 +791,16 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
                 stage_tables(m, tb);
                 tables_staged = true;
             }
-            prefetch_block(pf, words, b, n_bytes);
+            prefetch_block(pf, words, b, n_bytes, front_ok);
             commit_block(m, pf);
         }
         __syncthreads();
 
         const uint32_t lim = block_limit(n_bytes, b);
+        // `start` is always the start that (exit_rel, count) belong to; `cand` is the start
+        // the predecessor's exit asks for.  Only a walk moves cand into start, so whatever
+        // is stored -- also after giving up -- is self-consistent per lane.
+        uint32_t cand = (!FIRST && tid == 0) ? first_cand : start;
         for (uint32_t trip = 0;; ++trip) {
             if (trip == max_trips) {
                 // Codes that do not self-synchronise (near-fixed-length ones) would crawl
@@ -802,11 +817,11 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
             if (need) {
                 SubResult r;
                 if (lim != 0xffffffffu) {  // workgroup-uniform: the stream ends in this block
-                    r = warm ? walk_subsequence<0, true, true>(m, tb, tid, 0, lim, 0, 0, 0) : walk_subsequence<0, true, false>(m, tb, tid, start, lim, 0, 0, 0);
+                    r = warm ? walk_subsequence<0, true, true>(m, tb, tid, 0, lim, 0, 0, 0) : walk_subsequence<0, true, false>(m, tb, tid, cand, lim, 0, 0, 0);
                 } else if (warm) {
                     r = walk_subsequence<0, false, true>(m, tb, tid, 0, lim, 0, 0, 0);
                 } else {
-                    r = walk_subsequence<0, false, false>(m, tb, tid, start, lim, 0, 0, 0);
+                    r = walk_subsequence<0, false, false>(m, tb, tid, cand, lim, 0, 0, 0);
                 }
                 start = r.start_rel;
                 exit_rel = r.exit_rel;
@@ -817,9 +832,8 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
             __syncthreads();
             need = false;
             if (tid > 0 && live) {
-                const uint32_t in = m.exits[tid - 1];
-                need = in != start;
-                start = in;
+                cand = m.exits[tid - 1];
+                need = cand != start;
             }
             if (!__syncthreads_or(need)) break;
         }
@@ -1123,15 +1137,15 @@ static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticke
 
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
-                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket) {
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket, uint32_t flags) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
     if (SYNC_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (iter == 0)
-        hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips);
+        hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags);
     else
-        hipLaunchKernelGGL(k_dec_sync<false>, dim3(decode_grid(k_dec_sync<false>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips);
+        hipLaunchKernelGGL(k_dec_sync<false>, dim3(decode_grid(k_dec_sync<false>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags);
 }
 
 // Exhaustive synchronisation (see k_dec_maps).  Workspaces: lane_maps n_subs * stride,

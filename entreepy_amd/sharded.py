@@ -141,6 +141,60 @@ class ShardedCodec:
         byte1 = (layout["end_bit"] + 7) // 8
         return ctx.decode_body_device(layout["codebook"], enc[byte0:byte1], layout["n"], dec, start % 8)
 
+    # ------------------------------------------------------------- cold decode
+    def decode_cold(self, compressed, dec):
+        """Decode ONE .et stream (uint8 device tensor holding the file minus its first 4
+        bytes -- decode.zig's `compressed_text` -- on every rank, or at least this rank's
+        block range with 16 bytes on either side) across the ranks of the group, with no
+        side information.  The body is cut at multiples of 8 KiB from its 4-byte aligned
+        base; every rank synchronises its range (running in from the 16 bytes before it),
+        the ranks all-gather (start, exit, symbols), a rank whose start is not its
+        predecessor's exit repairs, and when all agree each rank writes its symbols to
+        `dec`.  Returns (symbols written by this rank, global index of its first symbol).
+        Expected rounds: 1 (a run-in is right 99.6 % of the time on text)."""
+        from .codec import parse_header
+
+        world, r = self.world, self.rank
+        head = compressed[: min(compressed.numel(), 8192)].cpu().numpy()
+        cb, n_symbols, body_off = parse_header(head)
+        ptr = compressed.data_ptr() + body_off
+        base_off = body_off - (ptr & 3)          # 4-byte aligned base of the body inside `compressed`
+        first_bit = (ptr & 3) * 8
+        stream = compressed[base_off:]
+        n_blocks = (stream.numel() + 8191) // 8192
+        lo_b, hi_b = r * n_blocks // world, (r + 1) * n_blocks // world
+        begin, end = lo_b * 8192, min(hi_b * 8192, stream.numel())
+        active = hi_b > lo_b and cb.raw.n_coded > 0 and n_symbols > 0
+        info = {"start_bit": 0, "exit_bit": 0, "n_symbols": 0}
+        if active:
+            info = self.ctx.decode_range_sync(cb, stream, begin, end, first_bit if lo_b == 0 else -1)
+        table = torch.zeros(world * 3, dtype=torch.int64, device=self.coll_device)
+        mine = torch.zeros(3, dtype=torch.int64, device=self.coll_device)
+        rounds = 0
+        while True:
+            rounds += 1
+            mine[0], mine[1], mine[2] = (info["start_bit"] if active else -1), (info["exit_bit"] if active else -1), info["n_symbols"]
+            dist.all_gather_into_tensor(table, mine, group=self.group)
+            t = table.view(world, 3).cpu().numpy()
+            # the exit that reaches rank q: the nearest active predecessor's (inactive ranks hold no blocks)
+            want = {}
+            prev_exit = first_bit
+            for q in range(world):
+                if t[q, 0] >= 0:
+                    want[q] = prev_exit
+                    prev_exit = int(t[q, 1])
+            wrong = [q for q in want if want[q] != int(t[q, 0])]
+            if not wrong:
+                break
+            if r in wrong:
+                info = self.ctx.decode_range_sync(cb, stream, begin, end, want[r])
+            assert rounds <= world + 1, "cold decode did not settle"
+        counts = t[:, 2]
+        first = int(counts[:r].sum())
+        take = max(0, min(int(counts[r]), n_symbols - first))
+        written = self.ctx.decode_range_write(take, dec) if active and take else 0
+        return written, first
+
     # ------------------------------------------------------------------ concat
     def gather_file(self, enc, layout):
         """Bit-offset-adjusted concatenation on rank 0 -> bytes (None elsewhere)."""

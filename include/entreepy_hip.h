@@ -167,6 +167,33 @@ int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body
                           size_t body_bytes, uint32_t start_bit, uint64_t n_symbols,
                           void *d_out, size_t cap, size_t *out_len);
 
+/* ---- one stream decoded on several GPUs (cold .et file, no side information) ---------- */
+/* The body is split at multiples of 8192 bytes counted from its 4-byte aligned base; every
+ * rank synchronises its own range, the ranks exchange (start, exit, symbols), a rank whose
+ * start differs from its predecessor's exit calls et_decode_range_sync again with that
+ * exit, and when all agree each rank writes its symbols (entreepy_amd/sharded.py
+ * decode_cold is the reference sequence).  decode.zig:143-203 has no counterpart: the
+ * reference walks the stream serially. */
+typedef struct et_range_info {
+    uint32_t start_bit;   /* where the first codeword of the range begins, bits from d_range */
+    uint32_t exit_bit;    /* first codeword boundary at or after the range end, bits past it */
+    uint64_t n_symbols;   /* codewords that begin inside the range */
+    uint32_t sweeps;      /* synchronisation launches of this call */
+    uint32_t reserved;
+} et_range_info;
+
+/* d_range: 4-byte aligned pointer to the range's first byte (range_bytes long; a multiple
+ * of 8192 unless the stream ends with it); tail_bytes more stream bytes are readable after
+ * it (0 only when the stream ends there, else >= 16); has_front: the 16 bytes before
+ * d_range are stream bytes too.  in_start_bit >= 0: the range's first codeword begins at
+ * that bit (rank 0: the body's start; later calls: the predecessor's exit_bit); -1: unknown,
+ * run in from the bytes in front (requires has_front).  Calling again for the same d_range
+ * with a corrected in_start_bit repairs the previous result instead of starting over. */
+int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const void *d_range, size_t range_bytes, size_t tail_bytes,
+                         int has_front, int32_t in_start_bit, et_range_info *info);
+/* Write the first max_symbols symbols of the range synchronised last into d_out. */
+int et_decode_range_write(et_ctx *ctx, uint64_t max_symbols, void *d_out, size_t cap, size_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,3 +141,85 @@ def test_large_stream_properties(ctx):
         assert bool(((got[:4] | ref[:4]) == ref[:4]).all()) and bool(((got[-4:] | ref[-4:]) == ref[-4:]).all())
         bit += end - local
     assert (bit + 7) // 8 == et_len
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_cold_decode_virtual_ranks(ranks, res_files):
+    """et_decode_range_sync / _write: one .et stream cut into block ranges, each handled by
+    its own et_ctx on the one GPU, exchange done by hand exactly as sharded.decode_cold
+    does over RCCL.  Includes a forced wrong start to exercise the repair call."""
+    import torch
+
+    import entreepy_amd as E
+    from oracle import oracle as O
+
+    for data in (corpus.text_like(2_000_003, 61), np.frombuffer(res_files["a_midsummer_nights_dream.txt"], dtype=np.uint8), corpus.uniform(300_000, 9, 1, 256)):
+        et = O.encode(data)
+        comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy()).cuda()
+        cb, n_symbols, body_off = E.parse_header(et[4:])
+        ptr = comp.data_ptr() + body_off
+        base_off, first_bit = body_off - (ptr & 3), (ptr & 3) * 8
+        stream = comp[base_off:]
+        n_blocks = (stream.numel() + 8191) // 8192
+        ctxs, infos, spans = [], [], []
+        for r in range(ranks):
+            lo, hi = r * n_blocks // ranks, (r + 1) * n_blocks // ranks
+            if hi == lo:
+                continue
+            c = E.Context(0)
+            c.use_torch_stream()
+            begin, end = lo * 8192, min(hi * 8192, stream.numel())
+            start = first_bit if lo == 0 else -1
+            if lo != 0 and r == 1:
+                # deliberately wrong known start: must be repaired below
+                start = 5 if begin else first_bit
+            infos.append(c.decode_range_sync(cb, stream, begin, end, start))
+            ctxs.append(c)
+            spans.append((begin, end))
+        for _ in range(ranks + 2):
+            prev, wrong = first_bit, []
+            for i, inf in enumerate(infos):
+                if inf["start_bit"] != prev:
+                    wrong.append((i, prev))
+                prev = inf["exit_bit"]
+            if not wrong:
+                break
+            for i, w in wrong:
+                infos[i] = ctxs[i].decode_range_sync(cb, stream, spans[i][0], spans[i][1], w)
+        else:
+            raise AssertionError("did not settle")
+        out, first = [], 0
+        for c, inf in zip(ctxs, infos):
+            take = max(0, min(inf["n_symbols"], n_symbols - first))
+            buf = torch.empty(inf["n_symbols"] + 64, dtype=torch.uint8, device="cuda")
+            m = c.decode_range_write(take, buf)
+            torch.cuda.synchronize()
+            out.append(buf[:m].cpu().numpy())
+            first += inf["n_symbols"]
+        assert np.concatenate(out).tobytes() == O.decode(et[4:])
+        for c in ctxs:
+            c.close()
+
+
+def test_cold_decode_over_rccl_world_size_1(ctx):
+    import torch
+    import torch.distributed as dist
+
+    from entreepy_amd import sharded
+    from oracle import oracle as O
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        data = corpus.text_like(1_500_000, 71)
+        et = O.encode(data)
+        comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy()).cuda()
+        dec = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+        codec = sharded.ShardedCodec(ctx, dist.group.WORLD, torch.device("cuda", 0))
+        m, first = codec.decode_cold(comp, dec)
+        torch.cuda.synchronize()
+        assert first == 0 and m == data.size and dec[:m].cpu().numpy().tobytes() == data.tobytes()
+    finally:
+        dist.destroy_process_group()

@@ -58,6 +58,50 @@ class OracleBackend:
         return len(res)
 
 
+    # -- cold decode of a block range (emulates et_decode_range_sync / _write) -----------
+    def decode_range_sync(self, cb, stream, begin, end, in_start_bit=-1):
+        table = {(int(cb.data[s]), int(cb.length[s])): s for s in range(256) if cb.length[s]}
+        maxlen = int(cb.length.max())
+        bits = np.unpackbits(stream.numpy())
+
+        def step(p):  # -> (symbol or None, length); no code: skip one bit, like the kernels
+            val = 0
+            for ln in range(1, maxlen + 1):
+                if p + ln > bits.size:
+                    return None, 0
+                val = (val << 1) | int(bits[p + ln - 1])
+                if (val, ln) in table:
+                    return table[(val, ln)], ln
+            return None, 1
+
+        if in_start_bit >= 0:
+            p = begin * 8 + in_start_bit
+        else:  # run in over the 128 bits in front of the range
+            p = begin * 8 - 128
+            while p < begin * 8:
+                _, ln = step(p)
+                if ln == 0:
+                    break
+                p += ln
+        start = p - begin * 8
+        syms = []
+        while p < end * 8:
+            sym, ln = step(p)
+            if ln == 0:
+                p = end * 8
+                break
+            if sym is not None:
+                syms.append(sym)
+            p += ln
+        self._range_syms = syms
+        return {"start_bit": start, "exit_bit": p - end * 8, "n_symbols": len(syms), "sweeps": 1}
+
+    def decode_range_write(self, max_symbols, out):
+        take = self._range_syms[:max_symbols]
+        out[: len(take)] = torch.tensor(take, dtype=torch.uint8)
+        return len(take)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -122,3 +166,44 @@ def test_plan_shards_offsets():
     assert sharded.owned_words(starts, 0)[0] == 0
     for r in range(2):
         assert sharded.owned_words(starts, r)[1] == sharded.owned_words(starts, r + 1)[0]
+
+
+def _cold_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from entreepy_amd import sharded
+
+        data = corpus.text_like(n, 78)
+        et = O.encode(data)
+        comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy())
+        codec = sharded.ShardedCodec(OracleBackend(), dist.group.WORLD, torch.device("cpu"))
+        dec = torch.zeros(n + 64, dtype=torch.uint8)
+        m, first = codec.decode_cold(comp, dec)
+        q.put((rank, first, dec[:m].numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cold_decode_across_ranks(world):
+    """sharded.decode_cold over gloo: block ranges, run-in starts, the (start, exit,
+    symbols) all-gather and the repair round; pieces concatenate to the input."""
+    n = 60000  # ~35 KB of body: 5 blocks of 8 KiB
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cold_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    data = corpus.text_like(n, 78).tobytes()
+    pos = 0
+    for rank, first, piece in got:
+        assert first == pos
+        pos += len(piece)
+    assert b"".join(g[2] for g in got) == data
