@@ -98,6 +98,19 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t *__restrict__ base, ui
     return c;
 }
 
+// Tile-level version: `interior` (workgroup-uniform, so a scalar branch) says the whole
+// tile lies inside the stream and every chunk of it is a plain 16-byte load.
+__device__ __forceinline__ Chunk load_chunk_in_tile(const uint8_t *__restrict__ base, uint64_t off, uint64_t lo, uint64_t hi, bool interior) {
+    if (interior) {
+        Chunk c;
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + off);
+        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+        c.valid = 0xffffu;
+        return c;
+    }
+    return load_chunk(base, off, lo, hi);
+}
+
 // --------------------------------------------------------------------------------
 // K1: byte histogram, LDS-privatised per lane bank
 // --------------------------------------------------------------------------------
@@ -128,6 +141,7 @@ __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict_
 
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(tid) * 16;
+        const bool interior = static_cast<uint64_t>(t) * tile_bytes >= lo && static_cast<uint64_t>(t + 1) * tile_bytes <= hi;
         // Four 16-byte loads in flight per lane: the kernel is latency-bound on HBM,
         // not on the (conflict-free) LDS atomics.
         for (uint32_t r0 = 0; r0 < rounds_per_tile; r0 += 4) {
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict_
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 c[u].valid = 0;
-                if (r0 + u < rounds_per_tile) c[u] = load_chunk(base, t0 + static_cast<uint64_t>(r0 + u) * ROUND_BYTES, lo, hi);
+                if (r0 + u < rounds_per_tile) c[u] = load_chunk_in_tile(base, t0 + static_cast<uint64_t>(r0 + u) * ROUND_BYTES, lo, hi, interior);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -300,13 +314,14 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
         uint32_t run = static_cast<uint32_t>(bit0 & 31);  // bit cursor relative to the tile's first word
         uint32_t flushed = 0;                             // ring words already stored
         const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(tid) * 16;
+        const bool interior = static_cast<uint64_t>(t) * tile_bytes >= lo && static_cast<uint64_t>(t + 1) * tile_bytes <= hi;
 
-        Chunk cur = load_chunk(base, t0, lo, hi);
+        Chunk cur = load_chunk_in_tile(base, t0, lo, hi, interior);
         for (uint32_t r = 0; r < rounds_per_tile; ++r) {
             Chunk nxt;
             nxt.valid = 0;
             nxt.w[0] = nxt.w[1] = nxt.w[2] = nxt.w[3] = 0;
-            if (r + 1 < rounds_per_tile) nxt = load_chunk(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi);
+            if (r + 1 < rounds_per_tile) nxt = load_chunk_in_tile(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi, interior);
 
             uint32_t code[16], len[16];
 #pragma unroll
@@ -337,35 +352,34 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
             uint32_t round_total;
             const uint32_t excl = block_exclusive_scan(tot, scratch[r & 1], &round_total);
 
-            uint32_t pos = run + excl;
-            uint32_t w = pos >> 5, fill = pos & 31;
-            unsigned long long acc = 0;
+            // Append: `part` is the open output word (bits filled from the top, `fill` of
+            // them); a piece goes in with one shift+or, and when the word completes it is
+            // OR-ed into the ring and the bits that did not fit start the next one.
+            const uint32_t pos = run + excl;
+            uint32_t fill = pos & 31;
+            uint32_t wbyte = ((pos >> 5) & (RING_WORDS - 1)) * 4;  // byte offset of the open word in the ring
+            uint32_t part = 0;
+            uint8_t *ring_bytes = reinterpret_cast<uint8_t *>(ring);
+#define ET_APPEND(piece_, len_)                                                                   \
+    do {                                                                                          \
+        part |= (piece_) >> fill;                                                                 \
+        const uint32_t nf_ = fill + (len_);                                                       \
+        if (nf_ >= 32) {                                                                          \
+            atomicOr(reinterpret_cast<uint32_t *>(ring_bytes + wbyte), part);                     \
+            part = ((piece_) << 1) << (31 - fill); /* what did not fit; 0 when fill == 0 */       \
+            wbyte = (wbyte + 4) & (RING_WORDS * 4 - 1);                                           \
+        }                                                                                         \
+        fill = nf_ & 31;                                                                          \
+    } while (0)
             if (!__any(wide)) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    acc |= static_cast<unsigned long long>(pcode[p]) << (32 - fill);
-                    fill += plen[p];
-                    if (fill >= 32) {
-                        atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
-                        acc <<= 32;
-                        fill -= 32;
-                        ++w;
-                    }
-                }
+                for (int p = 0; p < 8; ++p) ET_APPEND(pcode[p], plen[p]);
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    acc |= static_cast<unsigned long long>(code[k]) << (32 - fill);
-                    fill += len[k];
-                    if (fill >= 32) {
-                        atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
-                        acc <<= 32;
-                        fill -= 32;
-                        ++w;
-                    }
-                }
+                for (int k = 0; k < 16; ++k) ET_APPEND(code[k], len[k]);
             }
-            if (fill) atomicOr(&ring[w & (RING_WORDS - 1)], static_cast<uint32_t>(acc >> 32));
+#undef ET_APPEND
+            if (fill) atomicOr(reinterpret_cast<uint32_t *>(ring_bytes + wbyte), part);
             run += round_total;
             __syncthreads();
             flush_words<RING_WORDS>(f, flushed, run >> 5);
