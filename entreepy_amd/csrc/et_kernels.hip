@@ -371,7 +371,22 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
         }                                                                                         \
         fill = nf_ & 31;                                                                          \
     } while (0)
-            if (!__any(wide)) {
+            // Three levels, chosen per wavefront: quads (4 symbols per append, when every
+            // group of four codes fits 32 bits: text, ~97 % of the wavefront rounds), pairs,
+            // single symbols.
+            uint32_t qcode[4], qlen[4];
+            bool wide4 = wide;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t la = plen[2 * q];
+                qlen[q] = la + plen[2 * q + 1];
+                qcode[q] = pcode[2 * q] | (pcode[2 * q + 1] >> (la & 31u));
+                wide4 |= qlen[q] > 32;
+            }
+            if (!__any(wide4)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ET_APPEND(qcode[q], qlen[q]);
+            } else if (!__any(wide)) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) ET_APPEND(pcode[p], plen[p]);
             } else {
