@@ -323,31 +323,35 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
             nxt.w[0] = nxt.w[1] = nxt.w[2] = nxt.w[3] = 0;
             if (r + 1 < rounds_per_tile) nxt = load_chunk_in_tile(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi, interior);
 
-            uint32_t code[16], len[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint2 e = tab[(cur.w[k >> 2] >> (8 * (k & 3))) & 0xffu];
-                code[k] = e.x;
-                len[k] = e.y;
-            }
-            if (cur.valid != 0xffffu) {  // first/last chunk of the stream: bytes outside it carry no bits
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (!((cur.valid >> k) & 1u)) code[k] = len[k] = 0;
-            }
-            // Neighbouring symbols are merged into one piece of la + lb bits before the
-            // append step; a pair only fails to fit 32 bits when two codes of 17+ bits
-            // meet, which for Huffman codes of real text is a < 1e-9 event per pair.
-            uint32_t pcode[8], plen[8];
+            // Symbols are merged before the append step: neighbours into pairs, pairs into
+            // quads of la + lb + lc + ld bits.  A group only fails to fit 32 bits when long
+            // codes meet (for Huffman codes of text ~1e-4 per quad); the wavefront then
+            // falls back to pairs, then to single symbols, recomputing the table lookups
+            // (rare) instead of keeping 16 codes + 16 lengths live: 8 wavefronts per SIMD.
+            // Lanes holding the stream's first/last partial chunk take the last path.
+#define ET_ENTRY(k_) tab[(cur.w[(k_) >> 2] >> (8 * ((k_) & 3))) & 0xffu]
+            uint32_t qcode[4], qlen[4];
             uint32_t tot = 0;
-            bool wide = false;
+            bool wide4 = false, wide2 = false;  // some quad / some pair of this lane exceeds 32 bits
+            if (cur.valid == 0xffffu) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const uint32_t la = len[2 * p];
-                plen[p] = la + len[2 * p + 1];
-                pcode[p] = code[2 * p] | (code[2 * p + 1] >> (la & 31u));  // la == 32 with lb > 0 is `wide`
-                wide |= plen[p] > 32;
-                tot += plen[p];
+                for (int q = 0; q < 4; ++q) {
+                    const uint2 e0 = ET_ENTRY(4 * q), e1 = ET_ENTRY(4 * q + 1), e2 = ET_ENTRY(4 * q + 2), e3 = ET_ENTRY(4 * q + 3);
+                    const uint32_t l01 = e0.y + e1.y, l23 = e2.y + e3.y;
+                    const uint32_t c01 = e0.x | (e1.x >> (e0.y & 31u)), c23 = e2.x | (e3.x >> (e2.y & 31u));  // a 32-bit first code with a non-empty second is `wide2`
+                    qlen[q] = l01 + l23;
+                    qcode[q] = c01 | (c23 >> (l01 & 31u));
+                    wide2 |= l01 > 32 || l23 > 32;
+                    wide4 |= qlen[q] > 32;
+                    tot += qlen[q];
+                }
+                wide4 |= wide2;
+            } else {  // bytes outside the stream carry no bits
+                wide4 = wide2 = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) qcode[q] = qlen[q] = 0;
+                for (int k = 0; k < 16; ++k)
+                    if ((cur.valid >> k) & 1u) tot += ET_ENTRY(k).y;
             }
             uint32_t round_total;
             const uint32_t excl = block_exclusive_scan(tot, scratch[r & 1], &round_total);
@@ -371,29 +375,24 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
         }                                                                                         \
         fill = nf_ & 31;                                                                          \
     } while (0)
-            // Three levels, chosen per wavefront: quads (4 symbols per append, when every
-            // group of four codes fits 32 bits: text, ~97 % of the wavefront rounds), pairs,
-            // single symbols.
-            uint32_t qcode[4], qlen[4];
-            bool wide4 = wide;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t la = plen[2 * q];
-                qlen[q] = la + plen[2 * q + 1];
-                qcode[q] = pcode[2 * q] | (pcode[2 * q + 1] >> (la & 31u));
-                wide4 |= qlen[q] > 32;
-            }
             if (!__any(wide4)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ET_APPEND(qcode[q], qlen[q]);
-            } else if (!__any(wide)) {
+            } else if (!__any(wide2)) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) ET_APPEND(pcode[p], plen[p]);
+                for (int p = 0; p < 8; ++p) {
+                    const uint2 e0 = ET_ENTRY(2 * p), e1 = ET_ENTRY(2 * p + 1);
+                    ET_APPEND(e0.x | (e1.x >> (e0.y & 31u)), e0.y + e1.y);
+                }
             } else {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) ET_APPEND(code[k], len[k]);
+                for (int k = 0; k < 16; ++k) {
+                    uint2 e = ET_ENTRY(k);
+                    if (!((cur.valid >> k) & 1u)) e = make_uint2(0u, 0u);
+                    ET_APPEND(e.x, e.y);
+                }
             }
 #undef ET_APPEND
+#undef ET_ENTRY
             if (fill) atomicOr(reinterpret_cast<uint32_t *>(ring_bytes + wbyte), part);
             run += round_total;
             __syncthreads();
