@@ -349,3 +349,15 @@ def test_decode_rejects_malformed_streams(ctx):
     rng = np.random.default_rng(1)
     junk = good[:off] + rng.integers(0, 256, size=20000, dtype=np.uint8).tobytes()
     assert len(ctx.decode(junk)) <= n
+
+
+@pytest.mark.parametrize("p_common", [0.9, 0.99, 0.999])
+def test_heavily_skewed_streams(ctx, p_common):
+    """One symbol dominates: 1-bit codes, up to 65536 symbols per 8 KiB block (the write
+    kernel's multi-window path), and long codes for the rare symbols next to them."""
+    rng = np.random.default_rng(int(p_common * 1000))
+    n = 1_500_000
+    data = np.full(n, ord("a"), dtype=np.uint8)
+    rare = rng.random(n) > p_common
+    data[rare] = rng.integers(0, 200, size=int(rare.sum()), dtype=np.uint8)
+    _roundtrip(ctx, data)

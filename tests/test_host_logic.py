@@ -145,3 +145,20 @@ def test_cli_surface_without_gpu(tmp_path):
     assert bad.returncode != 0 and "invalid option: -x" in bad.stderr  # main.zig:116-118
     bad = subprocess.run([exe, "zip", "f"], capture_output=True, text=True)
     assert bad.returncode != 0 and "invalid command: zip" in bad.stderr  # main.zig:131-134
+
+
+def test_parse_header_reports_codes_longer_than_32_bits():
+    """Fibonacci counts give code lengths up to 44: the encoder reproduces the reference's
+    u32 truncation (Q3), the decoder refuses such a stream (the reference would index out
+    of bounds, Q9) with ET_ERR_UNSUPPORTED."""
+    fib = [1, 1]
+    while len(fib) < 45:
+        fib.append(fib[-1] + fib[-2])
+    h = np.zeros(256, dtype=np.uint64)
+    h[10:55] = fib
+    cb = E.Codebook.from_histogram(h)
+    assert cb.raw.max_length == 44
+    header = cb.header(int(h.sum()))
+    with pytest.raises(E.EntreepyError) as ei:
+        E.parse_header(header[4:])
+    assert ei.value.status == N.ET_ERR_UNSUPPORTED
