@@ -30,7 +30,9 @@ struct DevBuf {
 
 constexpr size_t HEADER_STAGE = 8192;  // >= 4631-byte worst-case header, padded
 constexpr size_t SUB_TABLE_ONLY = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) << et::DEC_SUB_BITS_MAX) * sizeof(uint16_t) + 64;
-constexpr size_t SUB_TABLE_BYTES = SUB_TABLE_ONLY + 256;  // the per-symbol code lengths ride behind the tables  // + slack for 16-byte rounded copies
+constexpr size_t SUB_TABLE_BYTES = SUB_TABLE_ONLY + 256;
+constexpr size_t DEC_TABLES_BYTES = (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2 + 1024 * sizeof(uint32_t) + 2 * SUB_TABLE_BYTES;
+//  // the per-symbol code lengths ride behind the tables  // + slack for 16-byte rounded copies
 
 }  // namespace
 
@@ -45,21 +47,18 @@ struct et_ctx {
     std::string err;
 
     // encode workspaces
-    DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, len_table, group_sum;
+    DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, group_sum;
     // decode workspaces
-    DevBuf sub_state, blk_exit, blk_count, blk_off, lut, longc, subt, flag;
+    DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag;  // lut: all decode tables, DEC_TABLES_BYTES
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
     // staging for the host-pointer entry points
     DevBuf io_in, io_out;
 
     // pinned host staging
     uint64_t *h_hist = nullptr;     // 256
-    uint32_t *h_enc = nullptr;      // 512 ({code,len} x 256)
-    uint32_t *h_len = nullptr;      // 256
+    uint32_t *h_enc = nullptr;      // 768: {code,len} x 256, then len x 256
     uint8_t *h_header = nullptr;    // HEADER_STAGE
     uint32_t *h_lut = nullptr;      // 1 << DEC_LUT_BITS_MAX
-    uint32_t *h_long = nullptr;     // 512
-    uint16_t *h_sub = nullptr;      // DEC_SUB_TABLES_MAX << DEC_SUB_BITS_MAX (+ 256 bytes: code length per symbol)
     uint64_t *h_scalar = nullptr;   // 4 (flag / totals)
 
     // link between et_histogram_device and et_encode_body_device
@@ -167,8 +166,7 @@ int ensure_encode_ws(et_ctx *ctx, uint32_t n_tiles) {
     ET_TRY(ensure(ctx, ctx->hist, 256 * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->tile_bits, (static_cast<size_t>(n_tiles) + 1) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->tile_off, (static_cast<size_t>(n_tiles) + 1) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->enc_table, 256 * 2 * sizeof(uint32_t)));
-    ET_TRY(ensure(ctx, ctx->len_table, 256 * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->enc_table, 768 * sizeof(uint32_t)));  // {code,len} x 256, then len x 256: one upload
     ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_tiles) / 1024 + 2) * sizeof(uint64_t)));
     return ET_OK;
 }
@@ -211,12 +209,11 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
         if (!long_codes) code = len ? (len == 32 ? code : (code & ((1u << len) - 1u)) << (32 - len)) : 0u;  // left-aligned
         ctx->h_enc[2 * s] = code;
         ctx->h_enc[2 * s + 1] = len;
-        ctx->h_len[s] = len;
+        ctx->h_enc[512 + s] = len;
     }
-    ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    ET_HIP(hipMemcpyAsync(ctx->len_table.p, ctx->h_len, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 768 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     et::launch_tile_scan(ctx->stream, static_cast<const uint32_t *>(ctx->tile_hist.p), g.n_tiles,
-                         static_cast<const uint32_t *>(ctx->len_table.p), static_cast<unsigned long long *>(ctx->tile_bits.p),
+                         static_cast<const uint32_t *>(ctx->enc_table.p) + 512, static_cast<unsigned long long *>(ctx->tile_bits.p),
                          static_cast<unsigned long long *>(ctx->group_sum.p), base_bit,
                          static_cast<unsigned long long *>(ctx->tile_off.p), out32);
     ET_HIP(hipGetLastError());
@@ -285,12 +282,9 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
     ctx->stream = ctx->own_stream;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hist), 256 * sizeof(uint64_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 512 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_len), 256 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 768 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_long), 1024 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_sub), 2 * SUB_TABLE_BYTES) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), DEC_TABLES_BYTES) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 4 * sizeof(uint64_t)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
@@ -305,13 +299,13 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->len_table, &ctx->group_sum,
-                      &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->longc, &ctx->subt, &ctx->flag,
+    DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->group_sum,
+                      &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->flag,
                       &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
                       &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
-    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_len, ctx->h_header, ctx->h_lut, ctx->h_long, ctx->h_sub, ctx->h_scalar};
+    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_header, ctx->h_lut, ctx->h_scalar};
     for (void *p : pinned)
         if (p) (void)hipHostFree(p);
     for (auto &e : ctx->ev)
@@ -372,9 +366,7 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->blk_count, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (n_blocks + 1) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->group_sum, (n_blocks / 1024 + 2) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
-    ET_TRY(ensure(ctx, ctx->longc, 1024 * sizeof(uint32_t)));
-    ET_TRY(ensure(ctx, ctx->subt, 2 * SUB_TABLE_BYTES));
+    ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
     return ET_OK;
 }
@@ -597,25 +589,25 @@ void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t 
 // DEC_WRITE_SYMS symbols; its own second-level tables and long list, since those depend on
 // the index width).
 int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *tb_out, et::DecodeTables *tb_write_out) {
-    ET_TRY(ensure(ctx, ctx->lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2));
-    ET_TRY(ensure(ctx, ctx->longc, 1024 * sizeof(uint32_t)));
-    ET_TRY(ensure(ctx, ctx->subt, 2 * SUB_TABLE_BYTES));
+    // one pinned block, one device block, one upload: [first-level x 2 | long lists | second-level (+ lengths) x 2]
+    ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
     ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
     HostDecodeTables ht, hw;
     uint32_t *h_lut_w = ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX);
-    uint32_t *h_long_w = ctx->h_long + 512;
-    uint16_t *h_sub_w = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_BYTES);
-    build_decode_tables(cb, ctx->lut_bits_max, et::DEC_SYNC_SYMS, ctx->h_lut, ctx->h_long, ctx->h_sub, &ht);
+    uint32_t *h_long = ctx->h_lut + (2u << et::DEC_LUT_BITS_MAX), *h_long_w = h_long + 512;
+    uint16_t *h_sub = reinterpret_cast<uint16_t *>(h_long + 1024);
+    uint16_t *h_sub_w = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(h_sub) + SUB_TABLE_BYTES);
+    build_decode_tables(cb, ctx->lut_bits_max, et::DEC_SYNC_SYMS, ctx->h_lut, h_long, h_sub, &ht);
     build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
-    std::memcpy(reinterpret_cast<uint8_t *>(ctx->h_sub) + SUB_TABLE_ONLY, cb->length, 256);
+    std::memcpy(reinterpret_cast<uint8_t *>(h_sub) + SUB_TABLE_ONLY, cb->length, 256);
     std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2, hipMemcpyHostToDevice, ctx->stream));
-    ET_HIP(hipMemcpyAsync(ctx->longc.p, ctx->h_long, 1024 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    ET_HIP(hipMemcpyAsync(ctx->subt.p, ctx->h_sub, 2 * SUB_TABLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
-    const uint8_t *subt = static_cast<const uint8_t *>(ctx->subt.p);
-    *tb_out = et::DecodeTables{static_cast<const uint32_t *>(ctx->lut.p), static_cast<const uint32_t *>(ctx->longc.p),
-                               reinterpret_cast<const uint16_t *>(subt), subt + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits, ht.n_sub};
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, DEC_TABLES_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t *d_lut = static_cast<const uint32_t *>(ctx->lut.p);
+    const uint32_t *d_long = d_lut + (2u << et::DEC_LUT_BITS_MAX);
+    const uint8_t *subt = reinterpret_cast<const uint8_t *>(d_long + 1024);
+    *tb_out = et::DecodeTables{d_lut, d_long, reinterpret_cast<const uint16_t *>(subt), subt + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits,
+                               ht.n_sub};
     *tb_write_out = et::DecodeTables{tb_out->lut + (1u << et::DEC_LUT_BITS_MAX), tb_out->longc + 512,
                                      reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES), subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
                                      hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub};
