@@ -7,6 +7,8 @@
 //                         bits_written counter turned into a scan over tiles)
 //   encode.zig:303-315 -> k_encode_tiles / k_encode_tiles_long    "K4"
 //   decode.zig:143-203 -> k_dec_sync, k_scan_*, k_dec_write       "D1..D3"
+//                         k_dec_maps, k_dec_compose, k_dec_chain, k_dec_resolve: the
+//                         bounded fallback for codes that do not self-synchronise
 //
 // Geometry shared by every kernel: workgroups of 256 threads (4 wavefronts of 64).
 // Encode side: a "round" is 4 KiB of input, one 16-byte load per lane, fully
@@ -534,9 +536,10 @@ __device__ __forceinline__ uint32_t load_be32_guarded(const uint32_t *__restrict
     return v;
 }
 
-// Staging.  A decode workgroup handles a chunk of DEC_CHUNK_BLOCKS consecutive 8 KiB
-// blocks: it copies the lookup tables into LDS once and then walks the blocks; while it
-// works on one block, the next block's words are already in flight into registers
+// Staging.  A decode workgroup handles chunks of SYNC_CHUNK / WRITE_CHUNK consecutive
+// 8 KiB blocks (et_kernels.h): it copies the lookup tables into LDS once and then walks
+// the blocks; while it works on one block, the next block's words are already in flight
+// into registers
 // (prefetch_block) and are written to LDS (commit_block) only when the current block
 // is done with the staging area.  LDS holds host-order words whose numeric MSB is the
 // first stream bit; logical word i of the stage = stream word
