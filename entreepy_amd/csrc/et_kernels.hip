@@ -744,6 +744,16 @@ __device__ __forceinline__ uint32_t block_limit(uint64_t n_bytes, uint64_t block
     return rel < DEC_STAGED_WORDS * 32 + 64 ? static_cast<uint32_t>(rel) : 0xffffffffu;
 }
 
+// Special blocks keep the LDS-window kernels: the stream's first block and the one or two
+// whose staged words reach the stream's end; everything else is "interior".
+__device__ __forceinline__ bool special_block(uint64_t b, uint64_t n_bytes) { return b == 0 || block_limit(n_bytes, b) != 0xffffffffu; }
+// workgroup i of a special-only launch (grid 3) looks at block 0, n-2, n-1
+__device__ __forceinline__ uint64_t special_candidate(uint32_t i, uint32_t n_blocks) {
+    if (i == 0) return 0;
+    const uint64_t c = static_cast<uint64_t>(n_blocks) + i;
+    return c >= 4 ? c - 3 : ~0ull;  // i = 1 -> n-2, i = 2 -> n-1; never block 0 again
+}
+
 // D1.  FIRST sweep: every subsequence runs in over the DEC_WARMUP_BITS before it (the
 // stream's very first one starts at first_bit, which is exact); lanes whose run-in
 // disagrees with their predecessor's exit are re-walked until the workgroup is
@@ -759,7 +769,8 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
                                                     uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed,
                                                     uint32_t *__restrict__ ticket, uint32_t max_trips, uint32_t flags) {
-    // flags (DEC_HAVE_START: first_bit is the exact start of subsequence 0; DEC_FRONT_OK:
+    // flags: DEC_SPECIAL_ONLY: handle only the special blocks (first, last one or two; one
+    // per workgroup), the others belong to k_dec_sync_reg.  (DEC_HAVE_START: first_bit is the exact start of subsequence 0; DEC_FRONT_OK:
     // the words before `words` belong to the stream) differ from {1, 0} only for a rank's
     // range of a stream decoded on several GPUs.
     const bool have_start = flags & DEC_HAVE_START, front_ok = flags & DEC_FRONT_OK;
@@ -786,8 +797,13 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
             b0 = static_cast<uint64_t>(blockIdx.x) * SYNC_CHUNK;
             __syncthreads();
         }
+        if (flags & DEC_SPECIAL_ONLY) {
+            if (!first_trip) break;
+            b0 = special_candidate(blockIdx.x, n_blocks);
+            if (b0 >= n_blocks || !special_block(b0, n_bytes)) break;
+        }
         if (b0 >= n_blocks) break;
-        const uint64_t b1 = b0 + SYNC_CHUNK < n_blocks ? b0 + SYNC_CHUNK : n_blocks;
+        const uint64_t b1 = (flags & DEC_SPECIAL_ONLY) ? b0 + 1 : (b0 + SYNC_CHUNK < n_blocks ? b0 + SYNC_CHUNK : n_blocks);
         if (FIRST) prefetch_block(pf, words, b0, n_bytes, front_ok);
     for (uint64_t b = b0; b < b1; ++b, ++round) {
         const uint64_t sub_g = b * BLOCK + tid;
@@ -1025,6 +1041,270 @@ __global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restric
     if (tid == static_cast<int>(n_live - 1)) blk_exit[b] = exit_rel;
 }
 
+// ---- register-window walk (interior blocks) ----------------------------------------------
+// The kernels above keep the block's bitstream in LDS and move a three-register window
+// over it (rotation selects, padded-address arithmetic, one LDS read per step).  For
+// blocks that lie wholly inside the stream -- all but the first and the last one or two
+// -- a lane instead loads the 9 (13 with the run-in) words of its subsequence straight
+// into registers and the walk is unrolled PER WORD: iteration w reads the window with one
+// v_alignbit_b32 from the fixed register pair (word w-1, word w) while the bit offset
+// `sh` stays in [1, 32], then sh -= 32.  No rotation, no window addressing, no bitstream
+// in LDS (k_dec_write_reg: 7 instead of 5 workgroups per CU), ~1/3 fewer instructions
+// per step.  Only the last word of a stretch needs the multi/single phase split.
+// (one out-of-line copy for the 15 unrolled step sites; everything by value: a reference
+// argument would push the caller's table pointers into scratch memory)
+__device__ __attribute__((noinline)) uint32_t long_code_cold(const uint16_t *sub, const uint32_t *longc, uint32_t n_long, uint32_t bits,
+                                                             uint32_t e, uint32_t window) {
+    const uint32_t lut_bits = bits & 0xffu, sub_bits = bits >> 8;
+    uint32_t hit = 0;
+    if ((e >> LUT_SUB_SHIFT) & 1u) hit = sub[((e & 0xffu) << sub_bits) | ((window << lut_bits) >> (32 - sub_bits))];
+    if (hit == 0) {  // as long_code
+        for (uint32_t i = 0; i < n_long; ++i) {
+            const uint32_t meta = longc[2 * i + 1], l = meta >> 8;
+            if (((window ^ longc[2 * i]) >> (32 - l)) == 0) {
+                hit = meta;
+                break;
+            }
+        }
+    }
+    return hit;
+}
+
+// Tables only (no bitstream): lut | sub | sym_len | [exits] | scratch | [stage]
+template <bool WITH_EXITS>
+__device__ __forceinline__ DecodeSmem carve_decode_smem_reg(const DecodeTables &tb) {
+    DecodeSmem m;
+    m.sdata = nullptr;
+    m.lut = reinterpret_cast<uint32_t *>(dec_smem_raw);
+    m.sub = reinterpret_cast<uint16_t *>(m.lut + (1u << tb.lut_bits));
+    m.sym_len = reinterpret_cast<uint8_t *>(m.lut + (1u << tb.lut_bits) + sub_words(tb));
+    m.exits = m.lut + (1u << tb.lut_bits) + sub_words(tb) + 64;
+    m.scratch = m.exits + (WITH_EXITS ? BLOCK : 0);
+    m.stage = reinterpret_cast<uint8_t *>(m.scratch + 8);
+    return m;
+}
+
+constexpr int RW_WORDS = 13;  // W[j] = stream word 8 * sub - 4 + j (host order): 4 run-in words, 8 own, 1 beyond
+
+// WRITE / WARM as walk_subsequence.  stage_* as there.
+template <int WRITE, bool WARM>
+__device__ __forceinline__ SubResult walk_regs(const DecodeSmem &m, const DecodeTables &tb, const uint32_t (&W)[RW_WORDS],
+                                               uint32_t start_rel, uint32_t stage_pos, uint32_t stage_lo, uint32_t stage_hi) {
+    const uint32_t idx_shift = 32 - tb.lut_bits;
+    // The only walk state is nsh = -(bit offset of the position in word w-1), in [-32, -1]
+    // while iteration w has work: the window is {word w-1, word w} >> (32 + nsh), and
+    // v_alignbit_b32 takes the shift modulo 32, i.e. nsh itself.
+    int nsh;
+    uint32_t count = 0;
+    SubResult res;
+    res.start_rel = start_rel;
+
+#define ET_RW_STEP(hi_, lo_, COUNTING, SINGLE)                                                             \
+    {                                                                                                      \
+        const uint32_t window_ = __builtin_amdgcn_alignbit(hi_, lo_, static_cast<uint32_t>(nsh));          \
+        const uint32_t e_ = m.lut[window_ >> idx_shift];                                                   \
+        uint32_t n_ = (e_ >> LUT_N_SHIFT) & 3u, syms_ = (SINGLE) ? (e_ & 0xffu) : e_;                      \
+        uint32_t len_ = (SINGLE) ? m.sym_len[e_ & 0xffu] : ((e_ >> LUT_LEN_SHIFT) & 15u);                  \
+        if (n_ == 0) {                                                                                     \
+            const uint32_t hit_ = long_code_cold(m.sub, tb.longc, tb.n_long, tb.lut_bits | (tb.sub_bits << 8), e_, window_); \
+            len_ = hit_ ? (hit_ >> 8) : 1u; /* no code: resynchronise bit by bit */                       \
+            syms_ = hit_ & 0xffu;                                                                          \
+            n_ = hit_ ? 1u : 0u;                                                                           \
+        } else if (SINGLE) {                                                                               \
+            n_ = 1;                                                                                        \
+        }                                                                                                  \
+        if (COUNTING) {                                                                                    \
+            if (WRITE == 1) {                                                                              \
+                const uint32_t o_ = stage_pos + count;                                                     \
+                if (SINGLE) {                                                                              \
+                    if (n_) m.stage[o_] = static_cast<uint8_t>(syms_);                                     \
+                } else { /* second byte first, at o + (n == 2); then the first symbol at o */             \
+                    m.stage[o_ + (n_ >> 1)] = static_cast<uint8_t>(syms_ >> 8);                            \
+                    m.stage[o_] = static_cast<uint8_t>(syms_);                                             \
+                }                                                                                          \
+            } else if (WRITE == 2) {                                                                       \
+                for (uint32_t j_ = 0; j_ < n_; ++j_) {                                                     \
+                    const uint32_t o_ = stage_pos + count + j_;                                            \
+                    if (o_ >= stage_lo && o_ < stage_hi) m.stage[o_ - stage_lo] = static_cast<uint8_t>(syms_ >> (8 * j_)); \
+                }                                                                                          \
+            }                                                                                              \
+            count += n_;                                                                                   \
+        }                                                                                                  \
+        nsh -= static_cast<int>(len_);                                                                     \
+    }
+// a word all of whose lut_bits windows lie before the stretch's limit: multi-symbol steps only
+#define ET_RW_WORD(hi_, lo_, COUNTING)                              \
+    while (nsh >= -32) ET_RW_STEP(hi_, lo_, COUNTING, false)        \
+    nsh += 32;
+// the word whose END is the stretch's limit (both stretches end on a word boundary: bit 0
+// and bit SUB_BITS of the subsequence): multi-symbol steps while lut_bits bits are left
+// before the limit, then single symbols.  Leaves nsh alone: -32 - nsh is how far the
+// last codeword reached past the limit.
+#define ET_RW_LAST_WORD(hi_, lo_, COUNTING)                                       \
+    while (nsh >= multi_floor) ET_RW_STEP(hi_, lo_, COUNTING, false)              \
+    while (nsh > -32) ET_RW_STEP(hi_, lo_, COUNTING, true)
+    const int multi_floor = static_cast<int>(tb.lut_bits) - 32;  // position <= limit - lut_bits
+
+    if (WARM) {
+        nsh = -32;  // DEC_WARMUP_BITS before the subsequence = first bit of W[0]
+        ET_RW_WORD(0u, W[0], false)
+        ET_RW_WORD(W[0], W[1], false)
+        ET_RW_WORD(W[1], W[2], false)
+        ET_RW_WORD(W[2], W[3], false)
+        ET_RW_LAST_WORD(W[3], W[4], false)
+        res.start_rel = static_cast<uint32_t>(-32 - nsh);  // in [0, 31]; nsh is already what the next line wants
+    } else {
+        nsh = -32 - static_cast<int>(start_rel);
+    }
+    ET_RW_WORD(W[3], W[4], true)  // only lanes at bit 0 (nsh == -32) act here
+    ET_RW_WORD(W[4], W[5], true)
+    ET_RW_WORD(W[5], W[6], true)
+    ET_RW_WORD(W[6], W[7], true)
+    ET_RW_WORD(W[7], W[8], true)
+    ET_RW_WORD(W[8], W[9], true)
+    ET_RW_WORD(W[9], W[10], true)
+    ET_RW_WORD(W[10], W[11], true)
+    ET_RW_LAST_WORD(W[11], W[12], true)
+#undef ET_RW_LAST_WORD
+#undef ET_RW_WORD
+#undef ET_RW_STEP
+    res.exit_rel = static_cast<uint32_t>(-32 - nsh);
+    res.count = count;
+    return res;
+}
+
+__device__ __forceinline__ void stage_tables_reg(const DecodeSmem &m, const DecodeTables &tb) { stage_tables(m, tb); }
+
+// The words of lane `sub_g`'s subsequence (interior block: every index is inside the stream).
+template <bool WITH_RUN_IN>
+__device__ __forceinline__ void load_window(uint32_t (&W)[RW_WORDS], const uint32_t *__restrict__ words, uint64_t sub_g) {
+    const uint32_t *src = words + sub_g * (SUB_BITS / 32) - 4;
+#pragma unroll
+    for (int j = WITH_RUN_IN ? 0 : 4; j < RW_WORDS; ++j) W[j] = __builtin_bswap32(src[j]);
+    if (!WITH_RUN_IN) W[0] = W[1] = W[2] = W[3] = 0;
+}
+
+// D1 for interior blocks; same protocol and state as k_dec_sync (which keeps the special
+// blocks: the stream's first block and the one or two it ends in).
+template <bool FIRST>
+__global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+                                                        DecodeTables tb, uint32_t *__restrict__ sub_state,
+                                                        uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_count,
+                                                        uint32_t *__restrict__ changed, uint32_t max_trips) {
+    const uint64_t b = blockIdx.x;
+    if (b >= n_blocks || special_block(b, n_bytes)) return;
+    const DecodeSmem m = carve_decode_smem_reg<true>(tb);
+    const int tid = threadIdx.x;
+    const uint64_t sub_g = b * BLOCK + tid;
+    uint32_t start = 0, exit_rel = 0, count = 0, cand = 0;
+    bool need = FIRST, warm = FIRST;
+    if (!FIRST) {
+        const uint32_t st = sub_state[sub_g];
+        start = cand = st & 0xffu;
+        exit_rel = (st >> 8) & 0xffu;
+        count = st >> 16;
+        if (tid == 0) {
+            cand = blk_exit[b - 1];
+            need = cand != start;
+            m.scratch[4] = need;
+        }
+        __syncthreads();
+        if (!m.scratch[4]) return;
+        if (tid == 0) *changed = 1;
+    }
+    stage_tables_reg(m, tb);
+    uint32_t W[RW_WORDS];
+    load_window<true>(W, words, sub_g);
+    __syncthreads();
+
+    for (uint32_t trip = 0;; ++trip) {
+        if (trip == max_trips) {  // see k_dec_sync
+            if (tid == 0) {
+                if (FIRST) atomicAdd(changed + 1, 1u);
+                else *changed = 1;
+                start = 0xffu;
+            }
+            break;
+        }
+        if (need) {
+            const SubResult r = warm ? walk_regs<0, true>(m, tb, W, 0, 0, 0, 0) : walk_regs<0, false>(m, tb, W, cand, 0, 0, 0);
+            start = r.start_rel;
+            exit_rel = r.exit_rel;
+            count = r.count;
+            warm = false;
+        }
+        m.exits[tid] = exit_rel;
+        __syncthreads();
+        need = false;
+        if (tid > 0) {
+            cand = m.exits[tid - 1];
+            need = cand != start;
+        }
+        if (!__syncthreads_or(need)) break;
+    }
+    sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
+    uint32_t total;
+    block_exclusive_scan(count, m.scratch, &total);
+    if (tid == 0) blk_count[b] = total;
+    if (tid == BLOCK - 1) blk_exit[b] = exit_rel;
+}
+
+// D3 for interior blocks (tickets of WRITE_CHUNK blocks, as k_dec_write).
+__global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+                                                         DecodeTables tb, const uint32_t *__restrict__ sub_state,
+                                                         const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
+                                                         uint8_t *__restrict__ out, uint32_t *__restrict__ ticket) {
+    const DecodeSmem m = carve_decode_smem_reg<false>(tb);
+    const int tid = threadIdx.x;
+    stage_tables_reg(m, tb);
+    for (;;) {
+        __syncthreads();  // tables staged (first trip); everybody is done with scratch[7] and the stage
+        if (tid == 0) m.scratch[7] = atomicAdd(ticket, WRITE_CHUNK);
+        __syncthreads();
+        const uint64_t b0 = m.scratch[7];
+        if (b0 >= n_blocks) break;
+        const uint64_t b1 = b0 + WRITE_CHUNK < n_blocks ? b0 + WRITE_CHUNK : n_blocks;
+        for (uint64_t b = b0; b < b1; ++b) {
+            if (special_block(b, n_bytes)) continue;  // k_dec_write
+            const uint64_t o0 = blk_off[b];
+            if (o0 >= n_symbols) break;  // pad bits decoded past the declared length; offsets only grow from here
+            const uint64_t sub_g = b * BLOCK + tid;
+            const uint32_t st = sub_state[sub_g];
+            const uint32_t start = st & 0xffu, count = st >> 16;
+            uint32_t W[RW_WORDS];
+            load_window<false>(W, words, sub_g);
+            uint32_t block_total;
+            const uint32_t my_off = block_exclusive_scan(count, m.scratch, &block_total);  // its barrier also separates the blocks' use of the stage
+
+            uint64_t o1 = o0 + block_total;
+            if (o1 > n_symbols) o1 = n_symbols;
+            const uint32_t n_out = static_cast<uint32_t>(o1 - o0);
+            const uint32_t phase = static_cast<uint32_t>(o0 & 15);  // stage offset of the first symbol
+            uint8_t *out_base = out + (o0 - phase);
+            const bool one_window = phase + block_total <= DEC_STAGE_BYTES && n_out == block_total;
+            for (uint32_t win = 0; win < phase + n_out; win += DEC_STAGE_BYTES) {
+                const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
+                const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
+                if (one_window) {
+                    if (count) walk_regs<1, false>(m, tb, W, start, my_lo, 0, 0);
+                } else if (my_lo < win_hi && my_hi > win) {
+                    walk_regs<2, false>(m, tb, W, start, my_lo, win, win_hi);
+                }
+                __syncthreads();
+                const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
+                for (uint32_t g = win + tid * 16; g < win_hi; g += BLOCK * 16) {
+                    if (g >= lo_valid && g + 16 <= win_hi) {
+                        *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(m.stage + (g - win));
+                    } else {
+                        for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = m.stage[k - win];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // D2 (scan of the workgroup symbol counts) is k_scan_local / k_scan_finish above.
 
 // D3: decode every subsequence from its synchronised start and write the symbols.
@@ -1033,7 +1313,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restric
 __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict__ words, uint64_t n_bytes, uint64_t n_subs,
                                                      uint32_t n_blocks, DecodeTables tb, const uint32_t *__restrict__ sub_state,
                                                      const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
-                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ ticket) {
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ ticket, uint32_t special_only) {
     const DecodeSmem m = carve_decode_smem<false>(tb);
     const int tid = threadIdx.x;
     stage_tables(m, tb);
@@ -1050,8 +1330,13 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
             b0 = static_cast<uint64_t>(blockIdx.x) * WRITE_CHUNK;
             __syncthreads();
         }
+        if (special_only) {  // one special block per workgroup (grid 3); the interior ones belong to k_dec_write_reg
+            if (!first_trip) break;
+            b0 = special_candidate(blockIdx.x, n_blocks);
+            if (b0 >= n_blocks || !special_block(b0, n_bytes)) break;
+        }
         if (b0 >= n_blocks) break;
-        const uint64_t b1 = b0 + WRITE_CHUNK < n_blocks ? b0 + WRITE_CHUNK : n_blocks;
+        const uint64_t b1 = special_only ? b0 + 1 : (b0 + WRITE_CHUNK < n_blocks ? b0 + WRITE_CHUNK : n_blocks);
         prefetch_block(pf, words, b0, n_bytes);
     for (uint64_t b = b0; b < b1; ++b) {
         const uint64_t o0 = blk_off[b];
@@ -1102,9 +1387,16 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
 // --------------------------------------------------------------------------------
 // launch wrappers (plain C++ callable; everything is enqueued on `stream`)
 // --------------------------------------------------------------------------------
-static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage, bool with_exits = true) {
+static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage, bool with_exits = true, bool with_stream = true) {
     const uint32_t sub_w = (((tb.n_sub << tb.sub_bits) + 7u) & ~7u) / 2;
-    return (DEC_SDATA_WORDS + (1u << tb.lut_bits) + sub_w + 64 + (with_exits ? BLOCK : 0) + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 : 0);
+    return ((with_stream ? DEC_SDATA_WORDS : 0) + (1u << tb.lut_bits) + sub_w + 64 + (with_exits ? BLOCK : 0) + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 : 0);
+}
+
+// ET_DEC_REG=0 keeps every block on the LDS-window kernels (A/B switch; default: interior
+// blocks take the register-window kernels).
+static bool use_reg_kernels(uint32_t n_blocks) {
+    static const bool on = [] { const char *e = getenv("ET_DEC_REG"); return !(e && e[0] == '0'); }();
+    return on && n_blocks > 3;
 }
 
 // Grid of the tile-striding encode kernels: the workgroups the device holds at once
@@ -1172,6 +1464,17 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
+    if (use_reg_kernels(n_blocks)) {
+        const size_t smem_reg = decode_smem_bytes(tb, false, true, false);
+        if (iter == 0) {
+            hipLaunchKernelGGL(k_dec_sync_reg<true>, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, max_trips);
+            hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
+        } else {
+            hipLaunchKernelGGL(k_dec_sync_reg<false>, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, max_trips);
+            hipLaunchKernelGGL(k_dec_sync<false>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
+        }
+        return;
+    }
     if (SYNC_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (iter == 0)
         hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags);
@@ -1209,8 +1512,14 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
     const size_t smem = decode_smem_bytes(tb, true, false);
-    if (WRITE_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket);
+    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+    if (use_reg_kernels(n_blocks)) {
+        const size_t smem_reg = decode_smem_bytes(tb, true, false, false);
+        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket);
+        hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u);
+        return;
+    }
+    hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 0u);
 }
 
 }  // namespace et
