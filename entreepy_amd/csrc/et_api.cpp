@@ -31,7 +31,8 @@ struct DevBuf {
 constexpr size_t HEADER_STAGE = 8192;  // >= 4631-byte worst-case header, padded
 constexpr size_t SUB_TABLE_ONLY = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) << et::DEC_SUB_BITS_MAX) * sizeof(uint16_t) + 64;
 constexpr size_t SUB_TABLE_BYTES = SUB_TABLE_ONLY + 256;
-constexpr size_t DEC_TABLES_BYTES = (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2 + 1024 * sizeof(uint32_t) + 2 * SUB_TABLE_BYTES;
+constexpr size_t DEC_STEPS_OFFSET = (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2 + 1024 * sizeof(uint32_t) + 2 * SUB_TABLE_BYTES;  // multiple of 64
+constexpr size_t DEC_TABLES_BYTES = DEC_STEPS_OFFSET + (sizeof(uint32_t) << et::DEC_STEP_BITS_MAX) + (et::DEC_STEP_SUB_WORDS + 4) * sizeof(uint32_t);
 //  // the per-symbol code lengths ride behind the tables  // + slack for 16-byte rounded copies
 
 }  // namespace
@@ -44,6 +45,7 @@ struct et_ctx {
     uint32_t force_rpt = 0;
     uint32_t lut_bits_max = et::DEC_LUT_BITS_DEFAULT;
     uint32_t lut_bits_write = et::DEC_LUT_BITS_WRITE;
+    uint32_t step_bits = et::DEC_STEP_BITS_DEFAULT;
     std::string err;
 
     // encode workspaces
@@ -272,6 +274,10 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     if (const char *env = std::getenv("ET_DEC_LUT_BITS")) {  // tuning knob: first-level decode table size
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 8 && v <= static_cast<long>(et::DEC_LUT_BITS_MAX)) ctx->lut_bits_max = static_cast<uint32_t>(v);
+    }
+    if (const char *env = std::getenv("ET_DEC_STEP_BITS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 8 && v <= static_cast<long>(et::DEC_STEP_BITS_MAX)) ctx->step_bits = static_cast<uint32_t>(v);
     }
     if (const char *env = std::getenv("ET_DEC_LUT_BITS_WRITE")) {
         const long v = std::strtol(env, nullptr, 10);
@@ -584,6 +590,50 @@ void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t 
     out->n_sub = n_sub;
 }
 
+// Step table of k_dec_sync_reg (et_kernels.h STEP_*): index = the next k bits, entry =
+// what a lookup adds to the walk state; second-level tables for the codes longer than k
+// follow it.  Returns k.
+uint32_t build_step_table(const et_codebook *cb, uint32_t bits_max, uint32_t *steps, uint32_t *sub_bits_out, uint32_t *n_sub_out) {
+    const uint32_t k = cb->max_length < bits_max ? (cb->max_length ? cb->max_length : 1) : bits_max;
+    const uint32_t n = 1u << k;
+    const uint32_t sub_bits = cb->max_length > k ? (cb->max_length - k < et::DEC_SUB_BITS_MAX ? cb->max_length - k : et::DEC_SUB_BITS_MAX) : 0;
+    uint32_t *ssub = steps + n;
+    std::vector<uint8_t> first(n, 0);  // length of the code that prefixes the index
+    std::vector<uint8_t> table_of(n, 0);  // 1 + second-level table of an index that is the prefix of longer codes
+    uint32_t n_sub = 0;
+    for (int s = 0; s < 256; ++s) {
+        const uint32_t len = cb->length[s];
+        if (!len) continue;
+        if (len <= k) {
+            std::memset(first.data() + (cb->data[s] << (k - len)), static_cast<int>(len), static_cast<size_t>(1) << (k - len));
+            continue;
+        }
+        const uint32_t prefix = cb->data[s] >> (len - k), rest_bits = len - k;
+        if (!table_of[prefix] && n_sub < 15 && ((n_sub + 1) << sub_bits) <= et::DEC_STEP_SUB_WORDS) {
+            std::memset(ssub + (static_cast<size_t>(n_sub) << sub_bits), 0, sizeof(uint32_t) << sub_bits);
+            table_of[prefix] = static_cast<uint8_t>(++n_sub);
+        }
+        if (table_of[prefix] && rest_bits <= sub_bits) {
+            uint32_t *t = ssub + (static_cast<size_t>(table_of[prefix] - 1) << sub_bits);
+            const uint32_t lo = (cb->data[s] & ((1u << rest_bits) - 1u)) << (sub_bits - rest_bits);
+            for (uint32_t i = 0; i < (1u << (sub_bits - rest_bits)); ++i) t[lo + i] = (1u << 16) - len;
+        }
+    }
+    for (uint32_t v = 0; v < n; ++v) {
+        uint32_t used = 0, cnt = 0;
+        for (;;) {
+            const uint32_t len = first[(v << used) & (n - 1)];
+            if (!len || used + len > k) break;
+            used += len;
+            ++cnt;
+        }
+        steps[v] = cnt ? (static_cast<uint32_t>(first[v]) << 28) + (cnt << 16) - used : et::STEP_ESCAPE + (static_cast<uint32_t>(table_of[v]) << 28);
+    }
+    *sub_bits_out = sub_bits;
+    *n_sub_out = n_sub;
+    return k;
+}
+
 // Build both table sets on the host and upload them: the sync/count sweeps (index
 // lut_bits_max, DEC_SYNC_SYMS symbols per entry) and the write kernel (index lut_bits_write,
 // DEC_WRITE_SYMS symbols; its own second-level tables and long list, since those depend on
@@ -602,15 +652,20 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
     std::memcpy(reinterpret_cast<uint8_t *>(h_sub) + SUB_TABLE_ONLY, cb->length, 256);
     std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, DEC_TABLES_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *h_steps = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->h_lut) + DEC_STEPS_OFFSET);
+    uint32_t step_sub_bits = 0, n_step_sub = 0;
+    const uint32_t step_bits = build_step_table(cb, ctx->step_bits, h_steps, &step_sub_bits, &n_step_sub);
+    const size_t step_bytes = (((static_cast<size_t>(1) << step_bits) + (static_cast<size_t>(n_step_sub) << step_sub_bits) + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t);
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, DEC_STEPS_OFFSET + step_bytes, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t *d_lut = static_cast<const uint32_t *>(ctx->lut.p);
     const uint32_t *d_long = d_lut + (2u << et::DEC_LUT_BITS_MAX);
     const uint8_t *subt = reinterpret_cast<const uint8_t *>(d_long + 1024);
     *tb_out = et::DecodeTables{d_lut, d_long, reinterpret_cast<const uint16_t *>(subt), subt + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits,
-                               ht.n_sub};
+                               ht.n_sub, reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET), step_bits,
+                               step_sub_bits, n_step_sub};
     *tb_write_out = et::DecodeTables{tb_out->lut + (1u << et::DEC_LUT_BITS_MAX), tb_out->longc + 512,
                                      reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES), subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
-                                     hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub};
+                                     hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub, nullptr, 0, 0, 0};
     return ET_OK;
 }
 

@@ -66,7 +66,25 @@ struct DecodeTables {
     uint32_t n_long;
     uint32_t sub_bits;
     uint32_t n_sub;
+    const uint32_t *steps;   // [1 << step_bits] packed walk increments for k_dec_sync_reg (STEP_* below), or null;
+                             // followed by n_step_sub second-level tables of 1 << step_sub_bits entries
+    uint32_t step_bits;
+    uint32_t step_sub_bits;
+    uint32_t n_step_sub;
 };
+
+// Step table of k_dec_sync_reg (no symbols, only how far a lookup moves the walk).  The
+// walk state X is one u32: bits 0..15 = STEP_BIAS - (bits walked), bits 16..27 = symbols
+// begun, bits 28..31 junk; entry = (len_first << 28) + (n << 16) - len_total is simply
+// ADDED to X (n = all the whole codes inside the index, len_first = length of the first
+// one for single steps).  No code inside the index: STEP_ESCAPE = one "symbol" of
+// STEP_ESCAPE_BITS bits, which throws the lane out of the word loop it is in; the loop's
+// exit test sees how far it flew and resolves the long code: bits 28..31 of the escape
+// entry = 1 + the second-level table (entries (1 << 16) - len, 0 = not here) indexed by the
+// step_sub_bits bits after the index, 0 = no table (tables in global memory, slow).
+constexpr uint32_t DEC_STEP_BITS_MAX = 13, DEC_STEP_BITS_DEFAULT = 12;
+constexpr uint32_t DEC_STEP_SUB_WORDS = 1024;                   // second-level entries, all tables together
+constexpr uint32_t STEP_BIAS = 0x4000, STEP_ESCAPE_BITS = 64, STEP_ESCAPE = (1u << 16) - STEP_ESCAPE_BITS;
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist);

@@ -1053,8 +1053,8 @@ __global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restric
 // per step.  Only the last word of a stretch needs the multi/single phase split.
 // (one out-of-line copy for the 15 unrolled step sites; everything by value: a reference
 // argument would push the caller's table pointers into scratch memory)
-__device__ __attribute__((noinline)) uint32_t long_code_cold(const uint16_t *sub, const uint32_t *longc, uint32_t n_long, uint32_t bits,
-                                                             uint32_t e, uint32_t window) {
+__device__ __forceinline__ uint32_t long_code_flat(const uint16_t *sub, const uint32_t *longc, uint32_t n_long, uint32_t bits, uint32_t e,
+                                                  uint32_t window) {
     const uint32_t lut_bits = bits & 0xffu, sub_bits = bits >> 8;
     uint32_t hit = 0;
     if ((e >> LUT_SUB_SHIFT) & 1u) hit = sub[((e & 0xffu) << sub_bits) | ((window << lut_bits) >> (32 - sub_bits))];
@@ -1068,6 +1068,10 @@ __device__ __attribute__((noinline)) uint32_t long_code_cold(const uint16_t *sub
         }
     }
     return hit;
+}
+__device__ __attribute__((noinline)) uint32_t long_code_cold(const uint16_t *sub, const uint32_t *longc, uint32_t n_long, uint32_t bits,
+                                                             uint32_t e, uint32_t window) {
+    return long_code_flat(sub, longc, n_long, bits, e, window);
 }
 
 // Tables only (no bitstream): lut | sub | sym_len | [exits] | scratch | [stage]
@@ -1173,6 +1177,159 @@ __device__ __forceinline__ SubResult walk_regs(const DecodeSmem &m, const Decode
     return res;
 }
 
+// One codeword at the top of `window`, from the tables in GLOBAL memory (the slow path of
+// walk_steps: its step table said "no whole code inside the index").  (len << 8) | sym, 0 = no code.
+__device__ __attribute__((noinline)) uint32_t decode_one_slow(const uint32_t *lut, const uint8_t *sym_len, const uint16_t *sub,
+                                                              const uint32_t *longc, uint32_t n_long, uint32_t bits, uint32_t window) {
+    const uint32_t e = lut[window >> (32 - (bits & 0xffu))];
+    if ((e >> LUT_N_SHIFT) & 3u) return (static_cast<uint32_t>(sym_len[e & 0xffu]) << 8) | (e & 0xffu);
+    return long_code_flat(sub, longc, n_long, bits, e, window);  // (inlined: a leaf function needs no stack)
+}
+
+__host__ __device__ __forceinline__ uint32_t step_table_words(const DecodeTables &tb) {
+    return ((1u << tb.step_bits) + (tb.n_step_sub << tb.step_sub_bits) + 3u) & ~3u;
+}
+
+// The synchronisation walk over a lane's registers: counts, keeps no symbols.  `steps` is
+// the step table in LDS (et_kernels.h STEP_*).  Bits are counted from A = 0 at 32 bits
+// before W[0]: the run-in starts at A = 32, the subsequence covers A in [160, 416).
+// Word iteration j (register pair W[j-1], W[j]) owns A in (32 j, 32 (j + 1)]; with
+// F = low half of X = STEP_BIAS - A that is F >= STEP_BIAS - 32 (j + 1), a 16-bit compare
+// against a constant, and v_alignbit_b32's shift (-A mod 32) is X's low five bits as they
+// are.  A step is: alignbit, shift, address, LDS read, add, compare.
+template <bool WARM>
+__device__ __forceinline__ SubResult walk_steps(const uint32_t *steps, const DecodeTables &tb, const uint32_t (&W)[RW_WORDS], uint32_t start_rel,
+                                                uint32_t (&ck)[8]) {
+    const uint32_t idx_shift = 32 - tb.step_bits;
+    const uint32_t *ssub = steps + (1u << tb.step_bits);
+    uint32_t X, e = 0;
+    SubResult res;
+    res.start_rel = start_rel;
+#define ET_F static_cast<uint16_t>(X)
+#define ET_SW_STEP(hi_, lo_) X += (e = steps[__builtin_amdgcn_alignbit(hi_, lo_, X) >> idx_shift]);
+// the code at X is longer than the index (`e` is its escape entry): second-level table, else the slow way
+#define ET_SW_SLOW(hi_, lo_)                                                                                           \
+    {                                                                                                                  \
+        const uint32_t w_ = __builtin_amdgcn_alignbit(hi_, lo_, X), t_ = e >> 28;                                      \
+        uint32_t add_ = 0;                                                                                             \
+        if (t_) add_ = ssub[((t_ - 1) << tb.step_sub_bits) | ((w_ << tb.step_bits) >> (32 - tb.step_sub_bits))];       \
+        if (add_ == 0) {                                                                                               \
+            const uint32_t hit_ = decode_one_slow(tb.lut, tb.sym_len, tb.sub, tb.longc, tb.n_long, tb.lut_bits | (tb.sub_bits << 8), w_); \
+            add_ = hit_ ? (1u << 16) - (hit_ >> 8) : ~0u; /* no code: one bit on, no symbol */                         \
+        }                                                                                                              \
+        X += add_;                                                                                                     \
+    }
+// word j, all of whose step_bits windows end before the stretch's limit.  A lane leaves the
+// inner loop at A in (32 (j+1), 32 (j+2)] -- or, after the escape pseudo-step, beyond that
+#define ET_SW_WORD(j_, hi_, lo_)                                                      \
+    for (;;) {                                                                        \
+        while (ET_F >= STEP_BIAS - 32 * ((j_) + 1)) ET_SW_STEP(hi_, lo_)              \
+        if (ET_F >= STEP_BIAS - 32 * ((j_) + 2)) break;                               \
+        X -= STEP_ESCAPE;                                                             \
+        ET_SW_SLOW(hi_, lo_)                                                          \
+    }
+// the word that ends at the stretch's limit LIM_ (in A): whole-index steps while
+// step_bits bits are left before the limit, then single codewords
+#define ET_SW_LAST_WORD(hi_, lo_, LIM_)                                               \
+    for (;;) {                                                                        \
+        while (ET_F >= multi_floor - (LIM_)) ET_SW_STEP(hi_, lo_)                     \
+        if (ET_F >= STEP_BIAS - (LIM_) - 32) break;                                   \
+        X -= STEP_ESCAPE;                                                             \
+        ET_SW_SLOW(hi_, lo_)                                                          \
+    }                                                                                 \
+    while (ET_F > STEP_BIAS - (LIM_)) {                                               \
+        e = steps[__builtin_amdgcn_alignbit(hi_, lo_, X) >> idx_shift];               \
+        if (static_cast<uint16_t>(e) != static_cast<uint16_t>(STEP_ESCAPE)) X += (1u << 16) - (e >> 28); \
+        else ET_SW_SLOW(hi_, lo_)                                                     \
+    }
+    const uint32_t multi_floor = STEP_BIAS + tb.step_bits;
+
+    if (WARM) {
+        X = STEP_BIAS - 32;
+        ET_SW_WORD(0, 0u, W[0])
+        ET_SW_WORD(1, W[0], W[1])
+        ET_SW_WORD(2, W[1], W[2])
+        ET_SW_WORD(3, W[2], W[3])
+        ET_SW_LAST_WORD(W[3], W[4], 160)
+        X &= 0xffffu;  // nothing counted so far
+        res.start_rel = STEP_BIAS - 160 - X;
+    } else {
+        X = STEP_BIAS - 160 - start_rel;
+    }
+    // ck[]: the state after each of the subsequence's first eight words (rewalk_steps)
+    ET_SW_WORD(4, W[3], W[4])  // only lanes that start at bit 0
+    ck[0] = X;
+    ET_SW_WORD(5, W[4], W[5])
+    ck[1] = X;
+    ET_SW_WORD(6, W[5], W[6])
+    ck[2] = X;
+    ET_SW_WORD(7, W[6], W[7])
+    ck[3] = X;
+    ET_SW_WORD(8, W[7], W[8])
+    ck[4] = X;
+    ET_SW_WORD(9, W[8], W[9])
+    ck[5] = X;
+    ET_SW_WORD(10, W[9], W[10])
+    ck[6] = X;
+    ET_SW_WORD(11, W[10], W[11])
+    ck[7] = X;
+    ET_SW_LAST_WORD(W[11], W[12], 416)
+    res.exit_rel = STEP_BIAS - 416 - (X & 0xffffu);
+    res.count = (X >> 16) & 0xfffu;
+    return res;
+}
+
+// Walk again from another start, given the checkpoints, exit and count of the walk before:
+// codes re-synchronise within a few codewords, so after a word or two the new walk stands
+// where the old one stood at the same word boundary -- from there on they are the same
+// walk, and only the symbol count has to be carried over.  (The wavefront skips the words
+// in which none of its lanes is still walking.)
+__device__ __forceinline__ SubResult rewalk_steps(const uint32_t *steps, const DecodeTables &tb, const uint32_t (&W)[RW_WORDS], uint32_t start_rel,
+                                                  uint32_t (&ck)[8], uint32_t old_exit, uint32_t old_count) {
+    const uint32_t idx_shift = 32 - tb.step_bits;
+    const uint32_t *ssub = steps + (1u << tb.step_bits);
+    const uint32_t multi_floor = STEP_BIAS + tb.step_bits;
+    uint32_t X = STEP_BIAS - 160 - start_rel, e = 0;
+    SubResult res;
+    res.start_rel = start_rel;
+    res.exit_rel = old_exit;
+    res.count = 0;
+    bool merged = false;
+    uint32_t shift = 0;
+#define ET_RW_CHECK(j_, hi_, lo_)                                                            \
+    if (!merged) {                                                                           \
+        ET_SW_WORD(j_, hi_, lo_)                                                             \
+        if (static_cast<uint16_t>(X) == static_cast<uint16_t>(ck[(j_) - 4])) {               \
+            merged = true;                                                                   \
+            res.count = (old_count + (X >> 16) - (ck[(j_) - 4] >> 16)) & 0xfffu;             \
+            shift = (res.count - old_count) << 16;                                           \
+        }                                                                                    \
+        ck[(j_) - 4] = X;                                                                    \
+    } else {                                                                                 \
+        ck[(j_) - 4] += shift; /* same walk from here on, other count before it */           \
+    }
+    ET_RW_CHECK(4, W[3], W[4])
+    ET_RW_CHECK(5, W[4], W[5])
+    ET_RW_CHECK(6, W[5], W[6])
+    ET_RW_CHECK(7, W[6], W[7])
+    ET_RW_CHECK(8, W[7], W[8])
+    ET_RW_CHECK(9, W[8], W[9])
+    ET_RW_CHECK(10, W[9], W[10])
+    ET_RW_CHECK(11, W[10], W[11])
+#undef ET_RW_CHECK
+    if (!merged) {
+        ET_SW_LAST_WORD(W[11], W[12], 416)
+        res.exit_rel = STEP_BIAS - 416 - (X & 0xffffu);
+        res.count = (X >> 16) & 0xfffu;
+    }
+    return res;
+}
+#undef ET_SW_LAST_WORD
+#undef ET_SW_WORD
+#undef ET_SW_SLOW
+#undef ET_SW_STEP
+#undef ET_F
+
 __device__ __forceinline__ void stage_tables_reg(const DecodeSmem &m, const DecodeTables &tb) { stage_tables(m, tb); }
 
 // The words of lane `sub_g`'s subsequence (interior block: every index is inside the stream).
@@ -1186,67 +1343,97 @@ __device__ __forceinline__ void load_window(uint32_t (&W)[RW_WORDS], const uint3
 
 // D1 for interior blocks; same protocol and state as k_dec_sync (which keeps the special
 // blocks: the stream's first block and the one or two it ends in).
-template <bool FIRST>
+template <bool FIRST, bool TICKET>
 __global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                         DecodeTables tb, uint32_t *__restrict__ sub_state,
                                                         uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_count,
-                                                        uint32_t *__restrict__ changed, uint32_t max_trips) {
-    const uint64_t b = blockIdx.x;
-    if (b >= n_blocks || special_block(b, n_bytes)) return;
-    const DecodeSmem m = carve_decode_smem_reg<true>(tb);
+                                                        uint32_t *__restrict__ changed, uint32_t *__restrict__ ticket, uint32_t max_trips, uint32_t chunk) {
+    // LDS: step table, its second-level tables | exits | scratch
+    uint32_t *steps = reinterpret_cast<uint32_t *>(dec_smem_raw);
+    const uint32_t step_words = step_table_words(tb);
+    DecodeSmem m;
+    m.exits = steps + step_words;
+    m.scratch = m.exits + BLOCK;
     const int tid = threadIdx.x;
-    const uint64_t sub_g = b * BLOCK + tid;
-    uint32_t start = 0, exit_rel = 0, count = 0, cand = 0;
-    bool need = FIRST, warm = FIRST;
-    if (!FIRST) {
-        const uint32_t st = sub_state[sub_g];
-        start = cand = st & 0xffu;
-        exit_rel = (st >> 8) & 0xffu;
-        count = st >> 16;
-        if (tid == 0) {
-            cand = blk_exit[b - 1];
-            need = cand != start;
-            m.scratch[4] = need;
-        }
-        __syncthreads();
-        if (!m.scratch[4]) return;
-        if (tid == 0) *changed = 1;
-    }
-    stage_tables_reg(m, tb);
-    uint32_t W[RW_WORDS];
-    load_window<true>(W, words, sub_g);
-    __syncthreads();
-
-    for (uint32_t trip = 0;; ++trip) {
-        if (trip == max_trips) {  // see k_dec_sync
-            if (tid == 0) {
-                if (FIRST) atomicAdd(changed + 1, 1u);
-                else *changed = 1;
-                start = 0xffu;
+    bool staged = false;
+    // TICKET: resident workgroups draw blocks from a counter and stage the table once;
+    // otherwise one block per workgroup (repair sweeps: most leave before staging anything).
+    for (uint64_t b = blockIdx.x, b_end = 0;; ++b) {
+        if (TICKET) {
+            __syncthreads();  // everybody is done with scratch and exits of the previous block
+            if (b >= b_end) {  // next chunk of consecutive blocks
+                if (tid == 0) m.scratch[7] = atomicAdd(ticket, chunk);
+                __syncthreads();
+                b = m.scratch[7];
+                b_end = b + chunk;
             }
-            break;
         }
-        if (need) {
-            const SubResult r = warm ? walk_regs<0, true>(m, tb, W, 0, 0, 0, 0) : walk_regs<0, false>(m, tb, W, cand, 0, 0, 0);
-            start = r.start_rel;
-            exit_rel = r.exit_rel;
-            count = r.count;
-            warm = false;
+        if (b >= n_blocks) break;
+        if (!special_block(b, n_bytes)) {
+            const uint64_t sub_g = b * BLOCK + tid;
+            uint32_t start = 0, exit_rel = 0, count = 0, cand = 0;
+            bool need = FIRST, warm = FIRST, skip = false, have_ck = false;
+            uint32_t ck[8];
+            if (!FIRST) {
+                const uint32_t st = sub_state[sub_g];
+                start = cand = st & 0xffu;
+                exit_rel = (st >> 8) & 0xffu;
+                count = st >> 16;
+                if (tid == 0) {
+                    cand = blk_exit[b - 1];
+                    need = cand != start;
+                    m.scratch[4] = need;
+                }
+                __syncthreads();
+                skip = !m.scratch[4];
+                if (!skip && tid == 0) *changed = 1;
+            }
+            if (!skip) {
+                uint32_t W[RW_WORDS];
+                load_window<true>(W, words, sub_g);
+                if (!staged) {
+                    for (uint32_t i = tid * 4; i < step_words; i += BLOCK * 4)
+                        *reinterpret_cast<uint4 *>(steps + i) = *reinterpret_cast<const uint4 *>(tb.steps + i);
+                    staged = true;
+                    __syncthreads();
+                }
+                for (uint32_t trip = 0;; ++trip) {
+                    if (trip == max_trips) {  // see k_dec_sync
+                        if (tid == 0) {
+                            if (FIRST) atomicAdd(changed + 1, 1u);
+                            else *changed = 1;
+                            start = 0xffu;
+                        }
+                        break;
+                    }
+                    if (need) {
+                        const SubResult r = warm      ? walk_steps<true>(steps, tb, W, 0, ck)
+                                            : have_ck ? rewalk_steps(steps, tb, W, cand, ck, exit_rel, count)
+                                                      : walk_steps<false>(steps, tb, W, cand, ck);
+                        have_ck = true;
+                        start = r.start_rel;
+                        exit_rel = r.exit_rel;
+                        count = r.count;
+                        warm = false;
+                    }
+                    m.exits[tid] = exit_rel;
+                    __syncthreads();
+                    need = false;
+                    if (tid > 0) {
+                        cand = m.exits[tid - 1];
+                        need = cand != start;
+                    }
+                    if (!__syncthreads_or(need)) break;
+                }
+                sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
+                uint32_t total;
+                block_exclusive_scan(count, m.scratch, &total);
+                if (tid == 0) blk_count[b] = total;
+                if (tid == BLOCK - 1) blk_exit[b] = exit_rel;
+            }
         }
-        m.exits[tid] = exit_rel;
-        __syncthreads();
-        need = false;
-        if (tid > 0) {
-            cand = m.exits[tid - 1];
-            need = cand != start;
-        }
-        if (!__syncthreads_or(need)) break;
+        if (!TICKET) break;
     }
-    sub_state[sub_g] = start | (exit_rel << 8) | (count << 16);
-    uint32_t total;
-    block_exclusive_scan(count, m.scratch, &total);
-    if (tid == 0) blk_count[b] = total;
-    if (tid == BLOCK - 1) blk_exit[b] = exit_rel;
 }
 
 // D3 for interior blocks (tickets of WRITE_CHUNK blocks, as k_dec_write).
@@ -1396,7 +1583,7 @@ static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage, 
 // blocks take the register-window kernels).
 static bool use_reg_kernels(uint32_t n_blocks) {
     static const bool on = [] { const char *e = getenv("ET_DEC_REG"); return !(e && e[0] == '0'); }();
-    return on && n_blocks > 3;
+    return on && n_blocks > 3;  // (fewer: nothing but special blocks)
 }
 
 // Grid of the tile-striding encode kernels: the workgroups the device holds at once
@@ -1465,12 +1652,18 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
     if (use_reg_kernels(n_blocks)) {
-        const size_t smem_reg = decode_smem_bytes(tb, false, true, false);
-        if (iter == 0) {
-            hipLaunchKernelGGL(k_dec_sync_reg<true>, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, max_trips);
+        const size_t smem_reg = (step_table_words(tb) + BLOCK + 8) * sizeof(uint32_t);
+        static const uint32_t chunk = [] { const char *e = getenv("ET_SYNC_REG_TICKET"); return e ? static_cast<uint32_t>(atoi(e)) : 4u; }();  // blocks per ticket (0: one workgroup per block); measured 0/4/8/16
+        const bool ticketed = chunk > 0;
+        if (iter == 0 && ticketed) {
+            (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk);
+            hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
+        } else if (iter == 0) {
+            hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         } else {
-            hipLaunchKernelGGL(k_dec_sync_reg<false>, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, max_trips);
+            hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u);
             hipLaunchKernelGGL(k_dec_sync<false>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         }
         return;

@@ -298,6 +298,19 @@ def test_skewed_then_flat_stream_hits_the_sync_cap(ctx):
     _roundtrip(ctx, np.concatenate([head, tail, head[:1000]]))
 
 
+@pytest.mark.parametrize("p_short", [0.02, 0.1, 0.3])
+def test_slowly_synchronising_streams(ctx, p_short):
+    """Mostly equal-length codes with a sprinkling of short ones: a wrong start survives for
+    many codewords, so lanes are re-walked several times and merge with their earlier walk
+    late (k_dec_sync_reg's checkpointed re-walk, trip cap, repair sweeps)."""
+    rng = np.random.default_rng(int(p_short * 1000))
+    n = (3 << 20) + 1234
+    flat = rng.integers(16, 16 + 160, size=n).astype(np.uint8)
+    short = rng.integers(1, 4, size=n).astype(np.uint8)
+    data = np.where(rng.random(n) < p_short, short, flat).astype(np.uint8)
+    _roundtrip(ctx, data)
+
+
 def test_property_random_streams(ctx):
     """hypothesis: arbitrary byte strings -- GPU encode == oracle encode, GPU decode ==
     oracle's intended decode (== input whenever the format is lossless)."""
