@@ -123,25 +123,36 @@ def main():
               "enc_total": 0.0, "dec_total": 0.0, "sync_launches": 0, "exchange": 0.0}
     state = {}
 
-    def step(record):
-        r = pipe.encode_shard(text, enc)
-        if record:
-            for k in ("hist", "enc_host", "enc_scan", "enc_body", "enc_total", "exchange"):
-                phases[k] += r["timings"][k]
+    def add_decode_timings():
+        t = ctx.timings("decode")
+        phases["dec_sync"] += t["sync_ms"]
+        phases["dec_sync_first"] += t["sync_first_ms"]
+        phases["dec_scan"] += t["scan_ms"]
+        phases["dec_body"] += t["body_ms"]
+        phases["dec_total"] += t["total_ms"]
+        phases["sync_launches"] += t["sync_iters"]
+
+    # The HIP events of every call are recorded inside the timed region; their elapsed
+    # times are READ where reading cannot stall the stream: the decode's after the next
+    # step's encode has been handed over (its histogram read-back waits for everything
+    # before it anyway), the encode's after the decode that follows it.
+    def step(record, first):
+        lazy = world == 1
+        r = pipe.encode_shard(text, enc, timings=not lazy)
+        if record and lazy and not first:
+            add_decode_timings()  # of the step before
         m = pipe.decode_shard(enc, r, dec)
         if record:
-            t = ctx.timings()
-            phases["dec_sync"] += t["sync_ms"]
-            phases["dec_sync_first"] += t["sync_first_ms"]
-            phases["dec_scan"] += t["scan_ms"]
-            phases["dec_body"] += t["body_ms"]
-            phases["dec_total"] += t["total_ms"]
-            phases["sync_launches"] += t["sync_iters"]
+            te = pipe.single_encode_timings() if lazy else r["timings"]
+            for k in ("hist", "enc_host", "enc_scan", "enc_body", "enc_total", "exchange"):
+                phases[k] += te[k]
+            if not lazy:
+                add_decode_timings()
         state.update(r)
         state["decoded"] = m
 
     for _ in range(args.warmup):
-        step(False)
+        step(False, True)
     torch.cuda.synchronize()
     assert state["decoded"] == n and torch.equal(dec[:n], text), "round trip is not the identity"
 
@@ -152,11 +163,13 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(True, i == 0)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if world == 1:
+        add_decode_timings()  # the last step's
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -67,6 +67,7 @@ SIGNATURES = {
     "et_ctx_set_tile_rounds": (ctypes.c_int, [_vp, ctypes.c_uint32]),
     "et_ctx_enable_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "et_last_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
+    "et_last_timings_of": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(Timings)]),
     "et_last_codebook": (ctypes.c_int, [_vp, _cbp]),
     "et_last_error": (ctypes.c_char_p, [_vp]),
     "et_strerror": (ctypes.c_char_p, [ctypes.c_int]),

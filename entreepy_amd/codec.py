@@ -178,9 +178,14 @@ class Context:
     def enable_timing(self, on=True):
         _check(N.lib().et_ctx_enable_timing(self._h, int(bool(on))), self._h)
 
-    def timings(self):
+    def timings(self, which=None):
+        """Phase timings of the last call (which=None), the last encode-side call ("encode")
+        or the last decode ("decode"); waits for that call's last event."""
         t = N.Timings()
-        _check(N.lib().et_last_timings(self._h, ctypes.byref(t)), self._h)
+        if which is None:
+            _check(N.lib().et_last_timings(self._h, ctypes.byref(t)), self._h)
+        else:
+            _check(N.lib().et_last_timings_of(self._h, {"encode": 0, "decode": 1}[which], ctypes.byref(t)), self._h)
         d = {k: getattr(t, k) for k, _ in N.Timings._fields_ if k not in ("reserved", "pad_")}
         d["exhaustive_sync"] = bool(t.reserved)
         return d

@@ -32,7 +32,8 @@ constexpr size_t HEADER_STAGE = 8192;  // >= 4631-byte worst-case header, padded
 constexpr size_t SUB_TABLE_ONLY = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) << et::DEC_SUB_BITS_MAX) * sizeof(uint16_t) + 64;
 constexpr size_t SUB_TABLE_BYTES = SUB_TABLE_ONLY + 256;
 constexpr size_t DEC_STEPS_OFFSET = (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2 + 1024 * sizeof(uint32_t) + 2 * SUB_TABLE_BYTES;  // multiple of 64
-constexpr size_t DEC_TABLES_BYTES = DEC_STEPS_OFFSET + (sizeof(uint32_t) << et::DEC_STEP_BITS_MAX) + (et::DEC_STEP_SUB_WORDS + 4) * sizeof(uint32_t);
+constexpr size_t DEC_TABLES_BYTES = DEC_STEPS_OFFSET + (sizeof(uint32_t) << et::DEC_STEP_BITS_MAX) + (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) +
+                                    2 * (et::DEC_STEP_SUB_WORDS + 4) * sizeof(uint32_t);
 //  // the per-symbol code lengths ride behind the tables  // + slack for 16-byte rounded copies
 
 }  // namespace
@@ -69,8 +70,13 @@ struct et_ctx {
     uint32_t hist_rpt = 0, hist_tiles = 0;
     bool hist_on_host = false;  // h_hist holds the counts of hist_text
 
-    hipEvent_t ev[6] = {};
-    et_timings tm = {};
+    hipEvent_t ev[12] = {};  // 0..5: encode calls, EV_DEC + 0..5: decode calls
+    et_timings tm_enc = {}, tm_dec = {};
+    // A full encode / body decode with timing on leaves its event arithmetic for the first
+    // et_last_timings[_of] call (which waits for the call's last event): the call itself
+    // then returns as asynchronously as it does with timing off.
+    bool pend_enc = false, pend_dec = false, pend_enc_bits = false, pend_dec_first = false;
+    int last_kind = 0;  // 0 encode, 1 decode
     et_codebook last_cb = {};
     bool have_cb = false;
 
@@ -176,6 +182,8 @@ int ensure_encode_ws(et_ctx *ctx, uint32_t n_tiles) {
 void record(et_ctx *ctx, int i) {
     if (ctx->timing) (void)hipEventRecord(ctx->ev[i], ctx->stream);
 }
+
+constexpr int EV_DEC = 6;
 
 float elapsed(et_ctx *ctx, int a, int b) {
     float ms = 0.f;
@@ -346,10 +354,33 @@ extern "C" int et_ctx_enable_timing(et_ctx *ctx, int on) {
     return ET_OK;
 }
 
-extern "C" int et_last_timings(const et_ctx *ctx, et_timings *out) {
-    if (!ctx || !out) return ET_ERR_ARG;
-    *out = ctx->tm;
+extern "C" int et_last_timings_of(et_ctx *ctx, int which, et_timings *out) {
+    if (!ctx || !out || which < 0 || which > 1) return ET_ERR_ARG;
+    DeviceGuard guard(ctx->device);
+    if (which == 0 && ctx->pend_enc) {
+        ET_HIP(hipEventSynchronize(ctx->ev[3]));
+        ctx->tm_enc.hist_ms = elapsed(ctx, 0, 1);
+        ctx->tm_enc.scan_ms = ctx->pend_enc_bits ? elapsed(ctx, 4, 2) : 0.f;
+        ctx->tm_enc.body_ms = elapsed(ctx, 2, 3);
+        ctx->tm_enc.total_ms = elapsed(ctx, 0, 3);
+        ctx->pend_enc = false;
+    }
+    if (which == 1 && ctx->pend_dec) {
+        ET_HIP(hipEventSynchronize(ctx->ev[EV_DEC + 3]));
+        ctx->tm_dec.sync_ms = elapsed(ctx, EV_DEC + 0, EV_DEC + 1);
+        ctx->tm_dec.scan_ms = elapsed(ctx, EV_DEC + 1, EV_DEC + 2);
+        ctx->tm_dec.body_ms = elapsed(ctx, EV_DEC + 2, EV_DEC + 3);
+        ctx->tm_dec.total_ms = elapsed(ctx, EV_DEC + 0, EV_DEC + 3);
+        ctx->tm_dec.sync_first_ms = ctx->pend_dec_first ? elapsed(ctx, EV_DEC + 0, EV_DEC + 5) : 0.f;
+        ctx->pend_dec = false;
+    }
+    *out = which == 0 ? ctx->tm_enc : ctx->tm_dec;
     return ET_OK;
+}
+
+extern "C" int et_last_timings(et_ctx *ctx, et_timings *out) {
+    if (!ctx) return ET_ERR_ARG;
+    return et_last_timings_of(ctx, ctx->last_kind, out);
 }
 
 extern "C" int et_last_codebook(const et_ctx *ctx, et_codebook *out) {
@@ -395,8 +426,10 @@ extern "C" int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, vo
     ET_HIP(hipMemcpyAsync(d_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->timing) {
         ET_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->tm = et_timings{};
-        ctx->tm.hist_ms = elapsed(ctx, 0, 1);
+        ctx->tm_enc = et_timings{};
+        ctx->tm_enc.hist_ms = elapsed(ctx, 0, 1);
+        ctx->pend_enc = false;
+        ctx->last_kind = 0;
     }
     return ET_OK;
 }
@@ -438,8 +471,10 @@ int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t 
     *end_bit = end;
     if (ctx->timing) {
         ET_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->tm.scan_ms = elapsed(ctx, 4, 2);
-        ctx->tm.body_ms = elapsed(ctx, 2, 3);
+        ctx->tm_enc.scan_ms = elapsed(ctx, 4, 2);
+        ctx->tm_enc.body_ms = elapsed(ctx, 2, 3);
+        ctx->pend_enc = false;
+        ctx->last_kind = 0;
     }
     return ET_OK;
 }
@@ -494,13 +529,11 @@ extern "C" int et_encode_device(et_ctx *ctx, const void *d_text, size_t n, void 
     }
     *out_len = header_len + static_cast<size_t>((bits + 7) / 8);  // encode.zig:318,336
     if (ctx->timing) {
-        ET_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->tm = et_timings{};
-        ctx->tm.hist_ms = elapsed(ctx, 0, 1);
-        ctx->tm.host_ms = static_cast<float>(t2 - t1);
-        ctx->tm.scan_ms = bits ? elapsed(ctx, 4, 2) : 0.f;
-        ctx->tm.body_ms = elapsed(ctx, 2, 3);
-        ctx->tm.total_ms = elapsed(ctx, 0, 3);
+        ctx->tm_enc = et_timings{};
+        ctx->tm_enc.host_ms = static_cast<float>(t2 - t1);
+        ctx->pend_enc = true;
+        ctx->pend_enc_bits = bits != 0;
+        ctx->last_kind = 0;
     }
     return ET_OK;
 }
@@ -634,6 +667,50 @@ uint32_t build_step_table(const et_codebook *cb, uint32_t bits_max, uint32_t *st
     return k;
 }
 
+// Step table of k_dec_write_reg (et_kernels.h WSTEP_*): as build_step_table, with symbols.
+uint32_t build_write_step_table(const et_codebook *cb, uint32_t bits_max, uint32_t *steps, uint32_t *sub_bits_out, uint32_t *n_sub_out) {
+    const uint32_t k = cb->max_length < bits_max ? (cb->max_length ? cb->max_length : 1) : bits_max;
+    const uint32_t n = 1u << k;
+    const uint32_t sub_bits = cb->max_length > k ? (cb->max_length - k < et::DEC_SUB_BITS_MAX ? cb->max_length - k : et::DEC_SUB_BITS_MAX) : 0;
+    uint32_t *wsub = steps + n;
+    std::vector<uint16_t> first(n, 0);  // (len << 8) | sym of the code that prefixes the index
+    std::vector<uint8_t> table_of(n, 0);
+    uint32_t n_sub = 0;
+    for (int s = 0; s < 256; ++s) {
+        const uint32_t len = cb->length[s];
+        if (!len) continue;
+        if (len <= k) {
+            const uint32_t lo = cb->data[s] << (k - len);
+            for (uint32_t i = 0; i < (1u << (k - len)); ++i) first[lo + i] = static_cast<uint16_t>((len << 8) | static_cast<uint32_t>(s));
+            continue;
+        }
+        const uint32_t prefix = cb->data[s] >> (len - k), rest_bits = len - k;
+        if (!table_of[prefix] && n_sub < 254 && ((n_sub + 1) << sub_bits) <= et::DEC_STEP_SUB_WORDS) {
+            std::memset(wsub + (static_cast<size_t>(n_sub) << sub_bits), 0, sizeof(uint32_t) << sub_bits);
+            table_of[prefix] = static_cast<uint8_t>(++n_sub);
+        }
+        if (table_of[prefix] && rest_bits <= sub_bits) {
+            uint32_t *t = wsub + (static_cast<size_t>(table_of[prefix] - 1) << sub_bits);
+            const uint32_t lo = (cb->data[s] & ((1u << rest_bits) - 1u)) << (sub_bits - rest_bits);
+            for (uint32_t i = 0; i < (1u << (sub_bits - rest_bits)); ++i) t[lo + i] = (static_cast<uint32_t>(s) << 16) | ((1u << 10) - len);
+        }
+    }
+    for (uint32_t v = 0; v < n; ++v) {
+        uint32_t used = 0, cnt = 0, syms = 0;
+        while (cnt < 2) {
+            const uint32_t f = first[(v << used) & (n - 1)], len = f >> 8;
+            if (!len || used + len > k) break;
+            syms |= (f & 0xffu) << (16 + 8 * cnt);
+            used += len;
+            ++cnt;
+        }
+        steps[v] = cnt ? syms | (((cnt << 10) - used) & 0xffffu) : (static_cast<uint32_t>(table_of[v]) << 24) | et::WSTEP_ESCAPE;
+    }
+    *sub_bits_out = sub_bits;
+    *n_sub_out = n_sub;
+    return k;
+}
+
 // Build both table sets on the host and upload them: the sync/count sweeps (index
 // lut_bits_max, DEC_SYNC_SYMS symbols per entry) and the write kernel (index lut_bits_write,
 // DEC_WRITE_SYMS symbols; its own second-level tables and long list, since those depend on
@@ -656,7 +733,11 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     uint32_t step_sub_bits = 0, n_step_sub = 0;
     const uint32_t step_bits = build_step_table(cb, ctx->step_bits, h_steps, &step_sub_bits, &n_step_sub);
     const size_t step_bytes = (((static_cast<size_t>(1) << step_bits) + (static_cast<size_t>(n_step_sub) << step_sub_bits) + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t);
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, DEC_STEPS_OFFSET + step_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *h_wsteps = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(h_steps) + step_bytes);  // right behind, one upload
+    uint32_t wstep_sub_bits = 0, n_wstep_sub = 0;
+    const uint32_t wstep_bits = build_write_step_table(cb, ctx->lut_bits_write, h_wsteps, &wstep_sub_bits, &n_wstep_sub);
+    const size_t wstep_bytes = (((static_cast<size_t>(1) << wstep_bits) + (static_cast<size_t>(n_wstep_sub) << wstep_sub_bits) + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t);
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, DEC_STEPS_OFFSET + step_bytes + wstep_bytes, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t *d_lut = static_cast<const uint32_t *>(ctx->lut.p);
     const uint32_t *d_long = d_lut + (2u << et::DEC_LUT_BITS_MAX);
     const uint8_t *subt = reinterpret_cast<const uint8_t *>(d_long + 1024);
@@ -665,7 +746,9 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
                                step_sub_bits, n_step_sub};
     *tb_write_out = et::DecodeTables{tb_out->lut + (1u << et::DEC_LUT_BITS_MAX), tb_out->longc + 512,
                                      reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES), subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
-                                     hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub, nullptr, 0, 0, 0};
+                                     hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub,
+                                     reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET + step_bytes), wstep_bits,
+                                     wstep_sub_bits, n_wstep_sub};
     return ET_OK;
 }
 
@@ -701,7 +784,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     et::DecodeTables tb, tb_write;
     ET_TRY(prepare_decode_tables(ctx, cb, &tb, &tb_write));
     const double t1 = now_ms();
-    record(ctx, 0);
+    record(ctx, EV_DEC + 0);
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
     uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
@@ -738,15 +821,15 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     if (!exhaustive) {
         ET_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(uint32_t), ctx->stream));
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4);
-        record(ctx, 5);
+        record(ctx, EV_DEC + 5);
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4);
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 2, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag + 2, flag + 4);
         ET_HIP(hipGetLastError());
         iters = 3;
-        record(ctx, 1);
+        record(ctx, EV_DEC + 1);
         ET_TRY(scan_and_total());
         ET_HIP(hipMemcpyAsync(h_flags, flag, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        record(ctx, 2);
+        record(ctx, EV_DEC + 2);
         if (can_speculate) {
             ET_TRY(write_symbols(n_symbols));
             wrote = true;
@@ -782,28 +865,25 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (iters > n_blocks + 4) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
     }
     if (exhaustive || more_sweeps) {
-        record(ctx, 1);
+        record(ctx, EV_DEC + 1);
         ET_TRY(scan_and_total());
-        record(ctx, 2);
+        record(ctx, EV_DEC + 2);
         ET_HIP(hipStreamSynchronize(ctx->stream));
     }
     const uint64_t decodable = ctx->h_scalar[1];
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
     if (n_out && !wrote) ET_TRY(write_symbols(n_out));
-    record(ctx, 3);
+    record(ctx, EV_DEC + 3);
     *out_len = static_cast<size_t>(n_out);
     if (ctx->timing) {
-        ET_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->tm = et_timings{};
-        ctx->tm.host_ms = static_cast<float>(t1 - t0);
-        ctx->tm.sync_ms = elapsed(ctx, 0, 1);
-        ctx->tm.scan_ms = elapsed(ctx, 1, 2);
-        ctx->tm.body_ms = elapsed(ctx, 2, 3);
-        ctx->tm.total_ms = elapsed(ctx, 0, 3);
-        ctx->tm.sync_iters = iters;
-        ctx->tm.reserved = exhaustive ? 1u : 0u;
-        ctx->tm.sync_first_ms = (iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2)) ? elapsed(ctx, 0, 5) : 0.f;
+        ctx->tm_dec = et_timings{};
+        ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
+        ctx->tm_dec.sync_iters = iters;
+        ctx->tm_dec.reserved = exhaustive ? 1u : 0u;
+        ctx->pend_dec = true;
+        ctx->pend_dec_first = iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2);
+        ctx->last_kind = 1;
     }
     return ET_OK;
 }

@@ -41,7 +41,7 @@ constexpr uint32_t DEC_WARMUP_BITS = DEC_FRONT_WORDS * 32;     // run-in before 
 constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GUARD_WORDS;
 constexpr uint32_t DEC_SDATA_WORDS = (DEC_STAGED_WORDS + (DEC_STAGED_WORDS >> 5) + 4) & ~3u;  // 1 pad word per 32
 constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: at most 4096 x u32 in LDS
-constexpr uint32_t DEC_LUT_BITS_WRITE = 10;                    // write kernel: 4 KiB table keeps it under 32 KiB of LDS (5 workgroups per CU)
+constexpr uint32_t DEC_LUT_BITS_WRITE = 11;                    // write kernels: measured 10 / 11 / 12 -> 0.65 / 0.60 / 0.68 ms at 1 GiB
 constexpr uint32_t DEC_LUT_BITS_DEFAULT = 11;                  // measured best on text (K = 10..11 tie, 12 and 9 slower)
 // first-level table entry (u32), indexed by the next lut_bits bits: bytes 0..2 = up to
 // three symbols whose codes all fit in the index, bits 24..27 = total length of those
@@ -83,6 +83,12 @@ struct DecodeTables {
 // entry = 1 + the second-level table (entries (1 << 16) - len, 0 = not here) indexed by the
 // step_sub_bits bits after the index, 0 = no table (tables in global memory, slow).
 constexpr uint32_t DEC_STEP_BITS_MAX = 13, DEC_STEP_BITS_DEFAULT = 12;
+// k_dec_write_reg's table (DecodeTables::steps of the write set) has the same shape with
+// symbols: state X = (stage address << 10) | (WSTEP_BIAS - bits walked); entry = sym2 << 24 |
+// sym1 << 16 | u16((n << 10) - len_total), n <= 2, whose sign-extended low half is added
+// to X; escape = WSTEP_ESCAPE in the low half, 1 + second-level table in bits 24..31;
+// second-level entries sym << 16 | ((1 << 10) - len), 0 = not here.
+constexpr uint32_t WSTEP_BIAS = 992, WSTEP_ESCAPE = (1u << 10) - 64;
 constexpr uint32_t DEC_STEP_SUB_WORDS = 1024;                   // second-level entries, all tables together
 constexpr uint32_t STEP_BIAS = 0x4000, STEP_ESCAPE_BITS = 64, STEP_ESCAPE = (1u << 16) - STEP_ESCAPE_BITS;
 

@@ -1088,6 +1088,10 @@ __device__ __forceinline__ DecodeSmem carve_decode_smem_reg(const DecodeTables &
     return m;
 }
 
+#ifndef ET_RW_WARM_WORDS
+#define ET_RW_WARM_WORDS 4
+#endif
+constexpr int RW_WARM_WORDS = ET_RW_WARM_WORDS;  // run-in of k_dec_sync_reg, in words (A/B knob; the loads stay)
 constexpr int RW_WORDS = 13;  // W[j] = stream word 8 * sub - 4 + j (host order): 4 run-in words, 8 own, 1 beyond
 
 // WRITE / WARM as walk_subsequence.  stage_* as there.
@@ -1245,10 +1249,10 @@ __device__ __forceinline__ SubResult walk_steps(const uint32_t *steps, const Dec
     const uint32_t multi_floor = STEP_BIAS + tb.step_bits;
 
     if (WARM) {
-        X = STEP_BIAS - 32;
-        ET_SW_WORD(0, 0u, W[0])
-        ET_SW_WORD(1, W[0], W[1])
-        ET_SW_WORD(2, W[1], W[2])
+        X = STEP_BIAS - 32 * (5 - RW_WARM_WORDS);  // the run-in starts with word W[4 - RW_WARM_WORDS]
+        if (RW_WARM_WORDS >= 4) ET_SW_WORD(0, 0u, W[0])
+        if (RW_WARM_WORDS >= 3) ET_SW_WORD(1, W[0], W[1])
+        if (RW_WARM_WORDS >= 2) ET_SW_WORD(2, W[1], W[2])
         ET_SW_WORD(3, W[2], W[3])
         ET_SW_LAST_WORD(W[3], W[4], 160)
         X &= 0xffffu;  // nothing counted so far
@@ -1436,19 +1440,116 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restri
     }
 }
 
+// The write walk over a lane's registers (et_kernels.h WSTEP_*): as walk_steps, with the
+// stage position riding in the state's upper bits.  A step stores two bytes: the second
+// symbol first, at (position after the step) - 1 -- for a one-symbol entry that is the
+// first symbol's own slot, which the first symbol then overwrites -- so no store is
+// conditional and none leaves the lane's own slots.
+//   MODE 1: X's upper bits are LDS addresses - 1 (the whole block fits the stage).
+//   MODE 2: they are positions in the block's output; bytes in [lo, hi) go to stage[pos - lo].
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+template <int MODE>
+__device__ __forceinline__ void walk_write(const uint32_t *wsteps, const uint8_t *sym_len, uint8_t *smem8, const DecodeTables &tb,
+                                           const uint32_t (&W)[RW_WORDS], uint32_t start_rel, uint32_t pos0, uint32_t lo, uint32_t hi,
+                                           uint32_t stage_off) {
+    const uint32_t idx_shift = 32 - tb.step_bits;
+    const uint32_t *wsub = wsteps + (1u << tb.step_bits);
+    const uint32_t multi_floor = WSTEP_BIAS + tb.step_bits;
+    uint32_t X = (pos0 << 10) | (WSTEP_BIAS - 160 - start_rel), e = 0;
+#define ET_F (X & 1023u)
+// MODE 1 positions are absolute LDS addresses minus one, used as integers (nothing to add,
+// and both of a step's stores get their -1 / +0 folded into the instruction's offset)
+#define ET_PUT(p_, v_)                                                                          \
+    {                                                                                           \
+        if (MODE == 1) *reinterpret_cast<lds_u8 *>(static_cast<uintptr_t>((p_) + 1u)) = static_cast<uint8_t>(v_); \
+        else if ((p_) - lo < hi - lo) smem8[stage_off + ((p_) - lo)] = static_cast<uint8_t>(v_); \
+    }
+#define ET_WW_STEP(hi_, lo_)                                                    \
+    {                                                                           \
+        e = wsteps[__builtin_amdgcn_alignbit(hi_, lo_, X) >> idx_shift];        \
+        const uint32_t p0_ = X >> 10;                                           \
+        X += e & 0xffffu;                                                       \
+        const uint32_t p1_ = X >> 10;                                           \
+        ET_PUT(p1_ - 1, e >> 24)                                                \
+        ET_PUT(p0_, e >> 16)                                                    \
+    }
+#define ET_WW_SLOW(hi_, lo_)                                                                                           \
+    {                                                                                                                  \
+        const uint32_t w_ = __builtin_amdgcn_alignbit(hi_, lo_, X), t_ = e >> 24;                                      \
+        uint32_t ent_ = 0;                                                                                             \
+        if (t_) ent_ = wsub[((t_ - 1) << tb.step_sub_bits) | ((w_ << tb.step_bits) >> (32 - tb.step_sub_bits))];      \
+        if (ent_ == 0) {                                                                                               \
+            const uint32_t hit_ = decode_one_slow(tb.lut, tb.sym_len, tb.sub, tb.longc, tb.n_long, tb.lut_bits | (tb.sub_bits << 8), w_); \
+            if (hit_) ent_ = ((hit_ & 0xffu) << 16) | ((1u << 10) - (hit_ >> 8));                                      \
+        }                                                                                                              \
+        if (ent_) {                                                                                                    \
+            ET_PUT(X >> 10, ent_ >> 16)                                                                                \
+            X += ent_ & 0xffffu;                                                                                       \
+        } else {                                                                                                       \
+            X -= 1; /* no code: one bit on, no symbol */                                                               \
+        }                                                                                                              \
+    }
+#define ET_WW_WORD(j_, hi_, lo_)                                                      \
+    for (;;) {                                                                        \
+        while (ET_F >= WSTEP_BIAS - 32 * ((j_) + 1)) ET_WW_STEP(hi_, lo_)             \
+        if (ET_F >= WSTEP_BIAS - 32 * ((j_) + 2)) break;                              \
+        X -= WSTEP_ESCAPE;                                                            \
+        ET_WW_SLOW(hi_, lo_)                                                          \
+    }
+    ET_WW_WORD(4, W[3], W[4])  // only lanes that start at bit 0
+    ET_WW_WORD(5, W[4], W[5])
+    ET_WW_WORD(6, W[5], W[6])
+    ET_WW_WORD(7, W[6], W[7])
+    ET_WW_WORD(8, W[7], W[8])
+    ET_WW_WORD(9, W[8], W[9])
+    ET_WW_WORD(10, W[9], W[10])
+    ET_WW_WORD(11, W[10], W[11])
+    for (;;) {  // the last word: two-symbol steps while step_bits bits are left, then one codeword at a time
+        while (ET_F >= multi_floor - 416) ET_WW_STEP(W[11], W[12])
+        if (ET_F >= WSTEP_BIAS - 416 - 32) break;
+        X -= WSTEP_ESCAPE;
+        ET_WW_SLOW(W[11], W[12])
+    }
+    while (ET_F > WSTEP_BIAS - 416) {
+        e = wsteps[__builtin_amdgcn_alignbit(W[11], W[12], X) >> idx_shift];
+        if ((e & 0xffffu) != WSTEP_ESCAPE) {
+            const uint32_t s1 = (e >> 16) & 0xffu;
+            ET_PUT(X >> 10, s1)
+            X += (1u << 10) - sym_len[s1];
+        } else {
+            ET_WW_SLOW(W[11], W[12])
+        }
+    }
+#undef ET_WW_WORD
+#undef ET_WW_SLOW
+#undef ET_WW_STEP
+#undef ET_PUT
+#undef ET_F
+}
+
 // D3 for interior blocks (tickets of WRITE_CHUNK blocks, as k_dec_write).
 __global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                          DecodeTables tb, const uint32_t *__restrict__ sub_state,
                                                          const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ ticket) {
-    const DecodeSmem m = carve_decode_smem_reg<false>(tb);
+    // LDS: step table, its second-level tables | code lengths | scratch | stage
+    uint32_t *wsteps = reinterpret_cast<uint32_t *>(dec_smem_raw);
+    const uint32_t step_words = step_table_words(tb);
+    uint8_t *sym_len = reinterpret_cast<uint8_t *>(wsteps + step_words);
+    uint32_t *scratch = wsteps + step_words + 64;
+    const uint32_t stage_off = (step_words + 64 + 8) * sizeof(uint32_t);
+    uint8_t *smem8 = reinterpret_cast<uint8_t *>(dec_smem_raw);
+    uint8_t *stage = smem8 + stage_off;
+    const uint32_t lds_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)stage));  // the stage's LDS address
     const int tid = threadIdx.x;
-    stage_tables_reg(m, tb);
+    for (uint32_t i = tid * 4; i < step_words; i += BLOCK * 4)
+        *reinterpret_cast<uint4 *>(wsteps + i) = *reinterpret_cast<const uint4 *>(tb.steps + i);
+    sym_len[tid] = tb.sym_len[tid];
     for (;;) {
         __syncthreads();  // tables staged (first trip); everybody is done with scratch[7] and the stage
-        if (tid == 0) m.scratch[7] = atomicAdd(ticket, WRITE_CHUNK);
+        if (tid == 0) scratch[7] = atomicAdd(ticket, WRITE_CHUNK);
         __syncthreads();
-        const uint64_t b0 = m.scratch[7];
+        const uint64_t b0 = scratch[7];
         if (b0 >= n_blocks) break;
         const uint64_t b1 = b0 + WRITE_CHUNK < n_blocks ? b0 + WRITE_CHUNK : n_blocks;
         for (uint64_t b = b0; b < b1; ++b) {
@@ -1461,7 +1562,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restr
             uint32_t W[RW_WORDS];
             load_window<false>(W, words, sub_g);
             uint32_t block_total;
-            const uint32_t my_off = block_exclusive_scan(count, m.scratch, &block_total);  // its barrier also separates the blocks' use of the stage
+            const uint32_t my_off = block_exclusive_scan(count, scratch, &block_total);  // its barrier also separates the blocks' use of the stage
 
             uint64_t o1 = o0 + block_total;
             if (o1 > n_symbols) o1 = n_symbols;
@@ -1473,17 +1574,17 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restr
                 const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
                 const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
                 if (one_window) {
-                    if (count) walk_regs<1, false>(m, tb, W, start, my_lo, 0, 0);
+                    if (count) walk_write<1>(wsteps, sym_len, smem8, tb, W, start, lds_stage + my_lo - 1u, 0, 0, 0);
                 } else if (my_lo < win_hi && my_hi > win) {
-                    walk_regs<2, false>(m, tb, W, start, my_lo, win, win_hi);
+                    walk_write<2>(wsteps, sym_len, smem8, tb, W, start, my_lo, win, win_hi, stage_off);
                 }
                 __syncthreads();
                 const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
                 for (uint32_t g = win + tid * 16; g < win_hi; g += BLOCK * 16) {
                     if (g >= lo_valid && g + 16 <= win_hi) {
-                        *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(m.stage + (g - win));
+                        *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(stage + (g - win));
                     } else {
-                        for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = m.stage[k - win];
+                        for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = stage[k - win];
                     }
                 }
                 __syncthreads();
@@ -1707,7 +1808,7 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     const size_t smem = decode_smem_bytes(tb, true, false);
     (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (use_reg_kernels(n_blocks)) {
-        const size_t smem_reg = decode_smem_bytes(tb, true, false, false);
+        const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
         hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket);
         hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u);
         return;

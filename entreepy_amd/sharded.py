@@ -71,22 +71,22 @@ class ShardedCodec:
         self._hdr_len = {}
 
     # ------------------------------------------------------------------ encode
-    def encode_shard(self, text, enc):
+    def encode_shard(self, text, enc, timings=True):
         """text: this rank's chunk (uint8 device tensor); enc: uint8 device buffer of
         encode_bound(len) + 64 bytes, 16-byte aligned.  Returns the layout dict
-        decode_shard / gather_file need."""
+        decode_shard / gather_file need.  timings=False (one GPU): do not wait for the
+        phase timings here ("timings" is None; fetch them later with
+        single_encode_timings(), e.g. once the decode has been enqueued)."""
         n = text.numel()
         ctx = self.ctx
         if self.group is None:
             et_len = ctx.encode_device(text, enc)
-            t = ctx.timings()
             hdr = self._hdr_len.get(et_len)
             if hdr is None:
                 cbk, _, off = _parse_device_header(enc, et_len)
                 hdr = self._hdr_len[et_len] = off + 4
             return {"world": 1, "single": True, "n": n, "et_len": et_len, "header_len": hdr, "body_bytes": et_len - hdr,
-                    "timings": {"hist": t["hist_ms"], "enc_host": t["host_ms"], "enc_scan": t["scan_ms"], "enc_body": t["body_ms"],
-                                "enc_total": t["total_ms"], "exchange": 0.0}}
+                    "timings": self.single_encode_timings() if timings else None}
 
         t_begin = time.perf_counter()
         ctx.histogram_device(text, self.hist)
@@ -114,6 +114,11 @@ class ShardedCodec:
                 "local_start_bit": local_start, "end_bit": end, "body_bytes": (starts[r + 1] - starts[r] + 7) // 8,
                 "timings": {"hist": hist_ms, "enc_host": (t_h1 - t_x1) * 1e3, "enc_scan": t.get("scan_ms", 0.0), "enc_body": t.get("body_ms", 0.0),
                             "enc_total": (t_end - t_begin) * 1e3, "exchange": (t_x1 - t_x0 + t_end - t_x2) * 1e3}}
+
+    def single_encode_timings(self):
+        t = self.ctx.timings("encode")
+        return {"hist": t["hist_ms"], "enc_host": t["host_ms"], "enc_scan": t["scan_ms"], "enc_body": t["body_ms"],
+                "enc_total": t["total_ms"], "exchange": 0.0}
 
     # ------------------------------------------------------------------ decode
     def decode_shard(self, enc, layout, dec):

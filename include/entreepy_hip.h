@@ -81,9 +81,14 @@ int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes);
 /* Tuning/test knob: force the encode tile to `rounds` x 4 KiB (1, 2, 4, 8 or 16);
  * 0 restores the size-based choice.  Results never depend on it. */
 int et_ctx_set_tile_rounds(et_ctx *ctx, uint32_t rounds);
-/* Record per-phase HIP events (small overhead); off by default. */
+/* Record per-phase HIP events (small overhead); off by default.  The calls stay as
+ * asynchronous as they are without: the event arithmetic happens in et_last_timings[_of],
+ * which waits for the call's last event.  et_last_timings = the last call's; _of: which =
+ * 0 the last encode-side call, 1 the last decode (separate event sets, so the encode
+ * figures can be fetched after the decode that followed has been enqueued). */
 int et_ctx_enable_timing(et_ctx *ctx, int on);
-int et_last_timings(const et_ctx *ctx, et_timings *out);
+int et_last_timings(et_ctx *ctx, et_timings *out);
+int et_last_timings_of(et_ctx *ctx, int which, et_timings *out);
 const char *et_last_error(const et_ctx *ctx);
 const char *et_strerror(int status);
 const char *et_version(void);
