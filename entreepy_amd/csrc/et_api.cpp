@@ -52,7 +52,7 @@ struct et_ctx {
     // encode workspaces
     DevBuf tile_hist, block_hist, hist, tile_bits, tile_off, enc_table, group_sum;
     // decode workspaces
-    DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag;  // lut: all decode tables, DEC_TABLES_BYTES
+    DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag, worklist;  // flag: [0..3] sweep flags, [4] ticket, [8..] worklist counts  // lut: all decode tables, DEC_TABLES_BYTES
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
     // staging for the host-pointer entry points
     DevBuf io_in, io_out;
@@ -315,7 +315,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->group_sum,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->flag,
-                      &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
+                      &ctx->worklist, &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
                       &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -402,6 +402,7 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->blk_exit, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_count, n_blocks * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (n_blocks + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->worklist, (n_blocks + 1) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->group_sum, (n_blocks / 1024 + 2) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
@@ -778,6 +779,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
     ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->worklist, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint32_t)));
 
     ctx->range.valid = false;  // shares the workspaces
     const double t0 = now_ms();
@@ -791,6 +793,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     uint32_t *blk_count = static_cast<uint32_t *>(ctx->blk_count.p);
     uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
     unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
+    uint32_t *worklist = static_cast<uint32_t *>(ctx->worklist.p);
 
     // D1..D3.  Sweep 0 runs in and repairs inside each block; sweeps 1 and 2 repair across
     // blocks (a sweep that changes nothing ends the search: on text sweep 1 fixes ~0.4 %
@@ -819,11 +822,13 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
     bool more_sweeps = false;
     if (!exhaustive) {
-        ET_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(uint32_t), ctx->stream));
+        ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4);
         record(ctx, EV_DEC + 5);
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4);
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 2, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag + 2, flag + 4);
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
+                            et::DEC_HAVE_START, worklist, flag + 8);
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 2, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag + 2, flag + 4,
+                            et::DEC_HAVE_START, worklist, flag + 9);
         ET_HIP(hipGetLastError());
         iters = 3;
         record(ctx, EV_DEC + 1);
@@ -856,7 +861,9 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     }
     while (more_sweeps) {
         ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, 0xffffffffu, sub_state, blk_exit, blk_count, flag, flag + 4);
+        ET_HIP(hipMemsetAsync(flag + 8, 0, sizeof(uint32_t), ctx->stream));
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, 0xffffffffu, sub_state, blk_exit, blk_count, flag, flag + 4,
+                            et::DEC_HAVE_START, worklist, flag + 8);
         ET_HIP(hipGetLastError());
         ++iters;
         ET_HIP(hipMemcpyAsync(h_flags, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -102,7 +102,7 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket,
-                     uint32_t flags = DEC_HAVE_START);
+                     uint32_t flags = DEC_HAVE_START, uint32_t *worklist = nullptr, uint32_t *n_work = nullptr);
 void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                            const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
                            uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,

@@ -1351,7 +1351,8 @@ template <bool FIRST, bool TICKET>
 __global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                         DecodeTables tb, uint32_t *__restrict__ sub_state,
                                                         uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_count,
-                                                        uint32_t *__restrict__ changed, uint32_t *__restrict__ ticket, uint32_t max_trips, uint32_t chunk) {
+                                                        uint32_t *__restrict__ changed, uint32_t *__restrict__ ticket, uint32_t max_trips, uint32_t chunk,
+                                                        const uint32_t *__restrict__ worklist, const uint32_t *__restrict__ n_work) {
     // LDS: step table, its second-level tables | exits | scratch
     uint32_t *steps = reinterpret_cast<uint32_t *>(dec_smem_raw);
     const uint32_t step_words = step_table_words(tb);
@@ -1361,8 +1362,17 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restri
     const int tid = threadIdx.x;
     bool staged = false;
     // TICKET: resident workgroups draw blocks from a counter and stage the table once;
-    // otherwise one block per workgroup (repair sweeps: most leave before staging anything).
+    // worklist (repair sweeps): the blocks k_dec_check found, strided over the grid;
+    // otherwise one block per workgroup.
+    const uint32_t n_wl = worklist ? *n_work : 0;
+    uint32_t wi = blockIdx.x;
     for (uint64_t b = blockIdx.x, b_end = 0;; ++b) {
+        if (!TICKET && worklist) {
+            if (wi >= n_wl) break;
+            __syncthreads();  // everybody is done with scratch and exits of the previous block
+            b = worklist[wi];
+            wi += gridDim.x;
+        }
         if (TICKET) {
             __syncthreads();  // everybody is done with scratch and exits of the previous block
             if (b >= b_end) {  // next chunk of consecutive blocks
@@ -1436,8 +1446,18 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restri
                 if (tid == BLOCK - 1) blk_exit[b] = exit_rel;
             }
         }
-        if (!TICKET) break;
+        if (!TICKET && !worklist) break;
     }
+}
+
+// Repair sweeps, step 1: one thread per block compares the start its first subsequence used
+// with the exit its predecessor ended on; the blocks that disagree (or gave up: start 0xff)
+// go on the worklist of k_dec_sync_reg<false> (special blocks look after themselves).
+__global__ __launch_bounds__(BLOCK) void k_dec_check(const uint32_t *__restrict__ sub_state, const uint32_t *__restrict__ blk_exit, uint32_t n_blocks,
+                                                     uint32_t *__restrict__ worklist, uint32_t *__restrict__ n_work) {
+    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b == 0 || b >= n_blocks) return;
+    if ((sub_state[static_cast<uint64_t>(b) * BLOCK] & 0xffu) != blk_exit[b - 1]) worklist[atomicAdd(n_work, 1u)] = b;
 }
 
 // The write walk over a lane's registers (et_kernels.h WSTEP_*): as walk_steps, with the
@@ -1748,7 +1768,8 @@ static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticke
 
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
-                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket, uint32_t flags) {
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket, uint32_t flags,
+                     uint32_t *worklist, uint32_t *n_work) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
@@ -1758,13 +1779,18 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
         const bool ticketed = chunk > 0;
         if (iter == 0 && ticketed) {
             (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk);
+            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         } else if (iter == 0) {
-            hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk);
+            hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         } else {
-            hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u);
+            if (worklist) {  // n_work zeroed by the caller
+                hipLaunchKernelGGL(k_dec_check, dim3((n_blocks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, sub_state, blk_exit, n_blocks, worklist, n_work);
+                hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks < 512 ? n_blocks : 512), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u, static_cast<const uint32_t *>(worklist), static_cast<const uint32_t *>(n_work));
+            } else {
+                hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+            }
             hipLaunchKernelGGL(k_dec_sync<false>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         }
         return;
