@@ -182,12 +182,13 @@ def main():
         sync_launches = phases["sync_launches"] / K
         kernels = {
             # name: (ms per launch, algorithmic bytes per launch); HIP events on the ctx stream.
-            # hist also holds k_hist_reduce (~12 us); the later sync sweeps (k_dec_sync<false>,
-            # ~0.1 ms each incl. the host's flag round trip) are in dec_sync, not listed here.
+            # hist also holds k_hist_reduce (~12 us); the sync and write figures include the
+            # 3-workgroup launches for the stream's first/last blocks (k_dec_sync<true>,
+            # k_dec_write); the repair sweeps (~0.02 ms) are in dec_sync, not listed here.
             "k_hist_tiles": (ms["hist"], n),
             "k_encode_tiles": (ms["enc_body"], n + m_bytes),
-            "k_dec_sync<true>": (ms["dec_sync_first"], m_bytes),
-            "k_dec_write": (ms["dec_body"], m_bytes + n),
+            "k_dec_sync_reg<true>": (ms["dec_sync_first"], m_bytes),
+            "k_dec_write_reg": (ms["dec_body"], m_bytes + n),
         }
         dominant = max(kernels, key=lambda k: kernels[k][0])
         d_ms, d_bytes = kernels[dominant]

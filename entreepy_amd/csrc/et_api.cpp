@@ -41,6 +41,7 @@ constexpr size_t DEC_TABLES_BYTES = DEC_STEPS_OFFSET + (sizeof(uint32_t) << et::
 struct et_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
+    et::SideLane side = {};  // second lane for the first/last-block launches of a decode
     hipStream_t stream = nullptr;
     bool timing = false;
     uint32_t force_rpt = 0;
@@ -295,6 +296,9 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     bool ok = guard.ok;
     ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
     ctx->stream = ctx->own_stream;
+    ok = ok && hipStreamCreateWithFlags(&ctx->side.stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hist), 256 * sizeof(uint64_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 768 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
@@ -325,6 +329,9 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
+    if (ctx->side.fork) (void)hipEventDestroy(ctx->side.fork);
+    if (ctx->side.join) (void)hipEventDestroy(ctx->side.join);
     delete ctx;
 }
 
@@ -794,6 +801,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
     unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
     uint32_t *worklist = static_cast<uint32_t *>(ctx->worklist.p);
+    static const bool use_side = [] { const char *e = std::getenv("ET_DEC_SIDE"); return !(e && e[0] == '0'); }();  // A/B switch
+    const et::SideLane *side = use_side ? &ctx->side : nullptr;
 
     // D1..D3.  Sweep 0 runs in and repairs inside each block; sweeps 1 and 2 repair across
     // blocks (a sweep that changes nothing ends the search: on text sweep 1 fixes ~0.4 %
@@ -814,7 +823,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         return ET_OK;
     };
     auto write_symbols = [&](uint64_t clamp) -> int {
-        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 4);
+        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 4, side);
         ET_HIP(hipGetLastError());
         return ET_OK;
     };
@@ -823,7 +832,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     bool more_sweeps = false;
     if (!exhaustive) {
         ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4);
+        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
+                            et::DEC_HAVE_START, nullptr, nullptr, side);
         record(ctx, EV_DEC + 5);
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
                             et::DEC_HAVE_START, worklist, flag + 8);

@@ -92,6 +92,13 @@ constexpr uint32_t WSTEP_BIAS = 992, WSTEP_ESCAPE = (1u << 10) - 64;
 constexpr uint32_t DEC_STEP_SUB_WORDS = 1024;                   // second-level entries, all tables together
 constexpr uint32_t STEP_BIAS = 0x4000, STEP_ESCAPE_BITS = 64, STEP_ESCAPE = (1u << 16) - STEP_ESCAPE_BITS;
 
+// The three-workgroup launches for the stream's first/last blocks take ~25 us each (one
+// block's latency); given a side lane they run beside the big launch instead of after it.
+struct SideLane {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist);
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
@@ -102,7 +109,7 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket,
-                     uint32_t flags = DEC_HAVE_START, uint32_t *worklist = nullptr, uint32_t *n_work = nullptr);
+                     uint32_t flags = DEC_HAVE_START, uint32_t *worklist = nullptr, uint32_t *n_work = nullptr, const SideLane *side = nullptr);
 void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                            const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
                            uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,
@@ -111,6 +118,6 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
                      unsigned long long *blk_off);
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
-                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket);
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr);
 
 }  // namespace et

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
     // or never -- costs nothing.
     for (bool first_trip = true;; first_trip = false) {
         uint64_t b0;
-        if (SYNC_TICKET) {
+        if (SYNC_TICKET && !(flags & DEC_SPECIAL_ONLY)) {
             __syncthreads();  // tables staged (first trip); everybody is done with scratch[7]
             if (tid == 0) m.scratch[7] = atomicAdd(ticket, SYNC_CHUNK);
             __syncthreads();
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
     Prefetch pf;
     for (bool first_trip = true;; first_trip = false) {  // chunks: see k_dec_sync
         uint64_t b0;
-        if (WRITE_TICKET) {
+        if (WRITE_TICKET && !special_only) {  // (a special-only launch must not eat tickets of k_dec_write_reg)
             __syncthreads();  // tables staged (first trip); everybody is done with scratch[7] and the stage
             if (tid == 0) m.scratch[7] = atomicAdd(ticket, WRITE_CHUNK);
             __syncthreads();
@@ -1766,10 +1766,25 @@ static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticke
     return n_chunks < g ? (n_chunks ? n_chunks : 1) : g;
 }
 
+// `special` = the stream the three-workgroup launch goes to: the side lane's (made to wait
+// for everything enqueued on `stream` so far) or `stream` itself; join_special makes
+// `stream` wait for it again.
+static hipStream_t fork_special(const SideLane *side, hipStream_t stream) {
+    if (!side) return stream;
+    (void)hipEventRecord(side->fork, stream);
+    (void)hipStreamWaitEvent(side->stream, side->fork, 0);
+    return side->stream;
+}
+static void join_special(const SideLane *side, hipStream_t stream) {
+    if (!side) return;
+    (void)hipEventRecord(side->join, side->stream);
+    (void)hipStreamWaitEvent(stream, side->join, 0);
+}
+
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket, uint32_t flags,
-                     uint32_t *worklist, uint32_t *n_work) {
+                     uint32_t *worklist, uint32_t *n_work, const SideLane *side) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
@@ -1779,8 +1794,10 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
         const bool ticketed = chunk > 0;
         if (iter == 0 && ticketed) {
             (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+            const hipStream_t special = fork_special(side, stream);
+            hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
             hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
-            hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
+            join_special(side, stream);
         } else if (iter == 0) {
             hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
@@ -1828,15 +1845,17 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
-                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket) {
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
     const size_t smem = decode_smem_bytes(tb, true, false);
     (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (use_reg_kernels(n_blocks)) {
         const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
+        const hipStream_t special = fork_special(side, stream);
+        hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u);
         hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket);
-        hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u);
+        join_special(side, stream);
         return;
     }
     hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 0u);
