@@ -1728,7 +1728,7 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
     const uint32_t grid = n_tiles < MAX_GRID ? n_tiles : MAX_GRID;  // over-subscribed on purpose: an exact-residency grid measured slower for K1
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
     hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist);
-    const uint32_t rgrid = grid < 64 ? grid : 64;
+    const uint32_t rgrid = grid < 512 ? grid : 512;
     hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
 }
 
