@@ -137,17 +137,14 @@ def main():
     # step's encode has been handed over (its histogram read-back waits for everything
     # before it anyway), the encode's after the decode that follows it.
     def step(record, first):
-        lazy = world == 1
-        r = pipe.encode_shard(text, enc, timings=not lazy)
-        if record and lazy and not first:
+        r = pipe.encode_shard(text, enc, timings=False)
+        if record and not first:
             add_decode_timings()  # of the step before
         m = pipe.decode_shard(enc, r, dec)
         if record:
-            te = pipe.single_encode_timings() if lazy else r["timings"]
+            te = pipe.encode_timings()
             for k in ("hist", "enc_host", "enc_scan", "enc_body", "enc_total", "exchange"):
                 phases[k] += te[k]
-            if not lazy:
-                add_decode_timings()
         state.update(r)
         state["decoded"] = m
 
@@ -168,8 +165,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world == 1:
-        add_decode_timings()  # the last step's
+    add_decode_timings()  # the last step's
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

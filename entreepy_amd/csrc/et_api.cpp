@@ -76,7 +76,7 @@ struct et_ctx {
     // A full encode / body decode with timing on leaves its event arithmetic for the first
     // et_last_timings[_of] call (which waits for the call's last event): the call itself
     // then returns as asynchronously as it does with timing off.
-    bool pend_enc = false, pend_dec = false, pend_enc_bits = false, pend_dec_first = false;
+    bool pend_enc = false, pend_dec = false, pend_enc_bits = false, pend_enc_shard = false, pend_dec_first = false;
     int last_kind = 0;  // 0 encode, 1 decode
     et_codebook last_cb = {};
     bool have_cb = false;
@@ -366,11 +366,13 @@ extern "C" int et_last_timings_of(et_ctx *ctx, int which, et_timings *out) {
     DeviceGuard guard(ctx->device);
     if (which == 0 && ctx->pend_enc) {
         ET_HIP(hipEventSynchronize(ctx->ev[3]));
-        ctx->tm_enc.hist_ms = elapsed(ctx, 0, 1);
+        if (!ctx->pend_enc_shard) {  // (a shard encode's histogram was a call of its own, hist_ms is its)
+            ctx->tm_enc.hist_ms = elapsed(ctx, 0, 1);
+            ctx->tm_enc.total_ms = elapsed(ctx, 0, 3);
+        }
         ctx->tm_enc.scan_ms = ctx->pend_enc_bits ? elapsed(ctx, 4, 2) : 0.f;
         ctx->tm_enc.body_ms = elapsed(ctx, 2, 3);
-        ctx->tm_enc.total_ms = elapsed(ctx, 0, 3);
-        ctx->pend_enc = false;
+        ctx->pend_enc = ctx->pend_enc_shard = false;
     }
     if (which == 1 && ctx->pend_dec) {
         ET_HIP(hipEventSynchronize(ctx->ev[EV_DEC + 3]));
@@ -477,11 +479,10 @@ int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t 
     }
     ET_TRY(run_body(ctx, cb, g, static_cast<uint32_t *>(d_out), start_bit, header_len ? ctx->h_header : nullptr, header_len, 2, 3));
     *end_bit = end;
-    if (ctx->timing) {
-        ET_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->tm_enc.scan_ms = elapsed(ctx, 4, 2);
-        ctx->tm_enc.body_ms = elapsed(ctx, 2, 3);
-        ctx->pend_enc = false;
+    if (ctx->timing) {  // hist_ms is already there (et_histogram_device); the rest when asked for
+        ctx->pend_enc = true;
+        ctx->pend_enc_bits = true;
+        ctx->pend_enc_shard = true;
         ctx->last_kind = 0;
     }
     return ET_OK;
@@ -541,6 +542,7 @@ extern "C" int et_encode_device(et_ctx *ctx, const void *d_text, size_t n, void 
         ctx->tm_enc.host_ms = static_cast<float>(t2 - t1);
         ctx->pend_enc = true;
         ctx->pend_enc_bits = bits != 0;
+        ctx->pend_enc_shard = false;
         ctx->last_kind = 0;
     }
     return ET_OK;

@@ -88,9 +88,7 @@ class ShardedCodec:
             return {"world": 1, "single": True, "n": n, "et_len": et_len, "header_len": hdr, "body_bytes": et_len - hdr,
                     "timings": self.single_encode_timings() if timings else None}
 
-        t_begin = time.perf_counter()
         ctx.histogram_device(text, self.hist)
-        hist_ms = ctx.timings()["hist_ms"]
         t_x0 = time.perf_counter()
         dist.all_gather_into_tensor(self.all_hists, self.hist.to(self.coll_device), group=self.group)
         hists = self.all_hists.view(self.world, 256).cpu().numpy().astype(np.uint64)
@@ -105,15 +103,22 @@ class ShardedCodec:
             local_start = starts[r] % 32
             end = ctx.encode_body_device(cb, text, enc, local_start)
         assert end - local_start == starts[r + 1] - starts[r]
-        t = ctx.timings()
-        if enc.is_cuda:
-            torch.cuda.synchronize(self.device)
-        t_end = time.perf_counter()
-        t_x2 = t_end
+        # host-side figures now; the GPU phases are read from the context's events on demand
+        self._host_timings = {"enc_host": (t_h1 - t_x1) * 1e3, "exchange": (t_x1 - t_x0) * 1e3}
         return {"world": self.world, "single": False, "n": n, "codebook": cb, "header_len": len(header) if r == 0 else 0, "starts": starts,
                 "local_start_bit": local_start, "end_bit": end, "body_bytes": (starts[r + 1] - starts[r] + 7) // 8,
-                "timings": {"hist": hist_ms, "enc_host": (t_h1 - t_x1) * 1e3, "enc_scan": t.get("scan_ms", 0.0), "enc_body": t.get("body_ms", 0.0),
-                            "enc_total": (t_end - t_begin) * 1e3, "exchange": (t_x1 - t_x0 + t_end - t_x2) * 1e3}}
+                "timings": self.encode_timings() if timings else None}
+
+    def encode_timings(self):
+        """Phase timings (ms) of the last encode_shard; waits for its last kernel.  With a
+        group, "exchange" is the wall clock of the histogram all-gather including the wait
+        for K1 before it, and enc_total the sum of the phases."""
+        if self.group is None:
+            return self.single_encode_timings()
+        t = self.ctx.timings("encode")
+        out = {"hist": t["hist_ms"], "enc_scan": t["scan_ms"], "enc_body": t["body_ms"], **self._host_timings}
+        out["enc_total"] = sum(out.values())
+        return out
 
     def single_encode_timings(self):
         t = self.ctx.timings("encode")

@@ -22,7 +22,7 @@ class OracleBackend:
     def __init__(self):
         self._t = {"hist_ms": 0.0, "scan_ms": 0.0, "body_ms": 0.0}
 
-    def timings(self):
+    def timings(self, which=None):
         return dict(self._t)
 
     def histogram_device(self, text, hist):
