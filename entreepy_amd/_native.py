@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ET_LIB_PATH: load another build of the same library (A/B variants in tools/ab_variants.sh)
 LIB_PATH = os.environ.get("ET_LIB_PATH") or os.path.join(_HERE, "libentreepy_hip.so")
 
-ET_OK, ET_ERR_EMPTY, ET_ERR_NOMEM, ET_ERR_CAP, ET_ERR_FORMAT, ET_ERR_HIP, ET_ERR_ARG, ET_ERR_UNSUPPORTED = range(8)
+ET_OK, ET_ERR_EMPTY, ET_ERR_NOMEM, ET_ERR_CAP, ET_ERR_FORMAT, ET_ERR_HIP, ET_ERR_ARG, ET_ERR_UNSUPPORTED, ET_ERR_IO = range(9)
 
 
 class Codebook(ctypes.Structure):
@@ -73,6 +73,8 @@ SIGNATURES = {
     "et_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "et_version": (ctypes.c_char_p, []),
     "et_encode_bound": (_sz, [_sz]),
+    "et_encode_fd": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "et_decode_fd": (ctypes.c_int, [_vp, ctypes.c_int, _sz, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "et_encode": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "et_decode": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "et_decoded_size": (ctypes.c_int, [_vp, _sz, _szp]),

@@ -190,6 +190,31 @@ class Context:
         d["exhaustive_sync"] = bool(t.reserved)
         return d
 
+    # -- whole calls, files (chunked pinned-buffer pipeline) -------------------------
+    def encode_file(self, in_path, out_path=None):
+        """c: in_path -> out_path (.et image); out_path None = code only (main.zig -t).
+        Returns (bytes read, bytes of .et produced)."""
+        return self._file_call(N.lib().et_encode_fd, in_path, out_path, ())
+
+    def decode_file(self, in_path, out_path=None, skip=4):
+        """d: in_path (a .et file; its first `skip` bytes are passed over as main.zig:204
+        does) -> out_path.  Returns (bytes consumed after the skip, bytes decoded)."""
+        return self._file_call(N.lib().et_decode_fd, in_path, out_path, (skip,))
+
+    def _file_call(self, fn, in_path, out_path, extra):
+        import os
+
+        fin = os.open(in_path, os.O_RDONLY)
+        fout = os.open(out_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644) if out_path is not None else -1
+        try:
+            a, b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            _check(fn(self._h, fin, *extra, fout, ctypes.byref(a), ctypes.byref(b)), self._h)
+            return a.value, b.value
+        finally:
+            os.close(fin)
+            if fout >= 0:
+                os.close(fout)
+
     # -- whole calls, host memory --------------------------------------------------
     def encode(self, text):
         a, p = _host_u8(text)

@@ -5,6 +5,9 @@
 // shim a maintainer would use instead).
 #include "entreepy_hip.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -147,15 +150,18 @@ int main(int argc, char **argv) {
     if (pr == 1) return 0;
     if (pr == 2) return 1;
 
-    std::vector<uint8_t> in;
-    if (!read_file(opt.in_path, in)) {
+    // The file goes through the library's chunked pinned-buffer pipeline (et_encode_fd /
+    // et_decode_fd) instead of main.zig:34-40's read-all; only `d -p`, which also wants the
+    // decoded bytes on stdout, reads it into memory the reference's way.
+    const int in_fd = ::open(opt.in_path.c_str(), O_RDONLY);
+    if (in_fd < 0) {
         std::fprintf(stderr, "error: FileNotFound: %s\n", opt.in_path.c_str());
         return 1;
     }
-    FILE *out_file = nullptr;
+    int out_fd = -1;
     if (!opt.dry) {  // main.zig:191-197: created (truncated) before coding starts
-        out_file = std::fopen(opt.out_path.c_str(), "wb+");
-        if (!out_file) {
+        out_fd = ::open(opt.out_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (out_fd < 0) {
             std::fprintf(stderr, "error: cannot create %s\n", opt.out_path.c_str());
             return 1;
         }
@@ -169,48 +175,60 @@ int main(int argc, char **argv) {
     }
 
     const auto t0 = std::chrono::steady_clock::now();
-    size_t written = 0, reported = 0;
-    std::vector<uint8_t> out;
+    size_t written = 0, reported = 0, in_size_bytes = 0;
     if (opt.mode == Mode::Compress) {
-        out.resize(et_encode_bound(in.size()));
-        rc = et_encode(ctx, in.data(), in.size(), out.data(), out.size(), &written);
+        rc = et_encode_fd(ctx, in_fd, out_fd, &in_size_bytes, &written);  // encode.zig:319: bytes land in the file
         if (rc == ET_OK) {
             if (opt.debug) {
                 et_codebook cb;
                 if (et_last_codebook(ctx, &cb) == ET_OK) dump_dictionary(cb);
             }
-            if (!opt.dry) std::fwrite(out.data(), 1, written, out_file);  // encode.zig:319
             if (opt.debug) std::printf("\nbits in output: %zu\n", written * 8);  // encode.zig:320
             reported = written;  // encode.zig:331,336: counts the bytes even with -t
         }
+    } else if (!opt.print) {
+        rc = et_decode_fd(ctx, in_fd, 4, out_fd, &in_size_bytes, &written);  // main.zig:204: text_in[4..]
+        if (rc == ET_OK && !opt.dry) reported = written;  // decode.zig:185-188
     } else {
-        if (in.size() < 9) {
+        std::vector<uint8_t> in, out;
+        if (!read_file(opt.in_path, in) || in.size() < 9) {
             rc = ET_ERR_FORMAT;
         } else {
+            in_size_bytes = in.size() - 4;
             size_t n = 0;
             et_decoded_size(in.data() + 4, in.size() - 4, &n);
             out.resize(n + 64);
             rc = et_decode(ctx, in.data() + 4, in.size() - 4, out.data(), out.size(), &written);  // main.zig:204
             if (rc == ET_OK) {
-                if (!opt.dry) { std::fwrite(out.data(), 1, written, out_file); reported = written; }  // decode.zig:185-188
-                if (opt.print) std::fwrite(out.data(), 1, written, stdout);                            // decode.zig:189
+                if (!opt.dry) {  // decode.zig:185-188
+                    size_t done = 0;
+                    while (done < written) {
+                        const ssize_t w = ::write(out_fd, out.data() + done, written - done);
+                        if (w <= 0) break;
+                        done += static_cast<size_t>(w);
+                    }
+                    reported = written;
+                }
+                std::fwrite(out.data(), 1, written, stdout);  // decode.zig:189
             }
         }
     }
     if (rc != ET_OK) {
         std::fprintf(stderr, "error: %s: %s\n", et_strerror(rc), et_last_error(ctx));
         et_ctx_destroy(ctx);
-        if (out_file) std::fclose(out_file);
+        ::close(in_fd);
+        if (out_fd >= 0) ::close(out_fd);
         return 1;
     }
     // encode.zig:334 / decode.zig:217 (decode reports the compressed_text length, i.e. file - 4)
-    const float in_size = static_cast<float>(opt.mode == Mode::Compress ? in.size() : in.size() - 4);
+    const float in_size = static_cast<float>(in_size_bytes);
     std::fprintf(stderr, "%s => %s\n", format_file_size(in_size).c_str(), format_file_size(static_cast<float>(reported)).c_str());
     if (opt.debug) {  // encode.zig:26-28 / decode.zig:15-17 (deferred to function exit)
         const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
         std::printf("time taken: %lld\xce\xbcs\n", static_cast<long long>(us));
     }
     et_ctx_destroy(ctx);
-    if (out_file) std::fclose(out_file);
+    ::close(in_fd);
+    if (out_fd >= 0) ::close(out_fd);
     return 0;
 }

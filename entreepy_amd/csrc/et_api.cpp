@@ -10,6 +10,9 @@
 // There is no CPU fallback anywhere in this file: without a usable HIP device every
 // entry point returns ET_ERR_HIP.
 #include "entreepy_hip.h"
+#include <sys/stat.h>
+
+#include "et_io.h"
 #include "et_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -55,8 +58,9 @@ struct et_ctx {
     // decode workspaces
     DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag, worklist;  // flag: [0..3] sweep flags, [4] ticket, [8..] worklist counts  // lut: all decode tables, DEC_TABLES_BYTES
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
-    // staging for the host-pointer entry points
+    // staging for the host-pointer / file-descriptor entry points
     DevBuf io_in, io_out;
+    et_io::Pipe *io = nullptr;  // pinned double buffer + copy threads, made on first use
 
     // pinned host staging
     uint64_t *h_hist = nullptr;     // 256
@@ -264,6 +268,7 @@ extern "C" const char *et_strerror(int status) {
         case ET_ERR_HIP: return "HIP runtime error";
         case ET_ERR_ARG: return "invalid argument";
         case ET_ERR_UNSUPPORTED: return "unsupported stream (code length > 32)";
+        case ET_ERR_IO: return "file read/write error";
         default: return "unknown status";
     }
 }
@@ -323,6 +328,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
                       &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    delete ctx->io;
     void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_header, ctx->h_lut, ctx->h_scalar};
     for (void *p : pinned)
         if (p) (void)hipHostFree(p);
@@ -548,21 +554,83 @@ extern "C" int et_encode_device(et_ctx *ctx, const void *d_text, size_t n, void 
     return ET_OK;
 }
 
-extern "C" int et_encode(et_ctx *ctx, const uint8_t *text, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
-    if (!ctx || !out || !out_len || (n && !text)) return ET_ERR_ARG;
+namespace {
+
+// The staging pipeline of the host-pointer / fd entry points (et_io.h).
+int ensure_io(et_ctx *ctx) {
+    if (ctx->io) return ET_OK;
+    size_t chunk = 32u << 20;
+    int threads = static_cast<int>(std::thread::hardware_concurrency() / 2);
+    if (threads > 8) threads = 8;
+    if (const char *e = std::getenv("ET_IO_CHUNK_MB")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 1024) chunk = static_cast<size_t>(v) << 20;
+    }
+    if (const char *e = std::getenv("ET_IO_THREADS")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 64) threads = static_cast<int>(v);
+    }
+    ctx->io = new (std::nothrow) et_io::Pipe();
+    if (!ctx->io || !ctx->io->init(chunk, threads)) {
+        delete ctx->io;
+        ctx->io = nullptr;
+        return fail(ctx, ET_ERR_NOMEM, "pinned staging buffers");
+    }
+    return ET_OK;
+}
+
+int io_status(et_ctx *ctx, int rc, const char *what) {
+    if (rc == 0) return ET_OK;
+    if (rc == -1) return fail(ctx, ET_ERR_IO, what);
+    return fail(ctx, ET_ERR_HIP, what, ctx->io->last_hip);
+}
+
+int file_size(int fd, uint64_t *size) {
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return -1;
+    *size = static_cast<uint64_t>(st.st_size);
+    return 0;
+}
+
+// encode: source -> io_in -> kernels -> io_out -> sink
+int encode_through_pipe(et_ctx *ctx, const et_io::HostEnd &src, size_t n, const et_io::HostEnd *dst, size_t cap, size_t *out_len) {
     if (n == 0) return fail(ctx, ET_ERR_EMPTY, "empty input");
-    DeviceGuard guard(ctx->device);
     const size_t bound = et_encode_bound(n);
+    ET_TRY(ensure_io(ctx));
     ET_TRY(ensure(ctx, ctx->io_in, n + 16));
     ET_TRY(ensure(ctx, ctx->io_out, bound + 16));
-    ET_HIP(hipMemcpyAsync(ctx->io_in.p, text, n, hipMemcpyHostToDevice, ctx->stream));
+    ET_TRY(io_status(ctx, ctx->io->upload(ctx->stream, ctx->io_in.p, src, n), "reading the input"));
     size_t len = 0;
     ET_TRY(et_encode_device(ctx, ctx->io_in.p, n, ctx->io_out.p, bound, &len));
     if (len > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
-    ET_HIP(hipMemcpyAsync(out, ctx->io_out.p, len, hipMemcpyDeviceToHost, ctx->stream));
-    ET_HIP(hipStreamSynchronize(ctx->stream));
+    if (dst) ET_TRY(io_status(ctx, ctx->io->download(ctx->stream, *dst, ctx->io_out.p, len), "writing the output"));
+    else ET_HIP(hipStreamSynchronize(ctx->stream));
     *out_len = len;
     return ET_OK;
+}
+
+}  // namespace
+
+extern "C" int et_encode(et_ctx *ctx, const uint8_t *text, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!ctx || !out || !out_len || (n && !text)) return ET_ERR_ARG;
+    DeviceGuard guard(ctx->device);
+    et_io::HostEnd src, dst;
+    src.ptr = const_cast<uint8_t *>(text);
+    dst.ptr = out;
+    return encode_through_pipe(ctx, src, n, &dst, cap, out_len);
+}
+
+extern "C" int et_encode_fd(et_ctx *ctx, int in_fd, int out_fd, size_t *in_len, size_t *out_len) {
+    if (!ctx || !in_len || !out_len || in_fd < 0) return ET_ERR_ARG;
+    *in_len = *out_len = 0;
+    uint64_t n = 0;
+    if (file_size(in_fd, &n) != 0) return fail(ctx, ET_ERR_IO, "input is not a regular file");
+    DeviceGuard guard(ctx->device);
+    et_io::HostEnd src, dst;
+    src.fd = in_fd;
+    dst.fd = out_fd;
+    *in_len = static_cast<size_t>(n);
+    return encode_through_pipe(ctx, src, static_cast<size_t>(n), out_fd >= 0 ? &dst : nullptr, ~static_cast<size_t>(0), out_len);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1023,24 +1091,55 @@ extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t le
     return et_decode_body_device(ctx, &cb, static_cast<const uint8_t *>(d_compressed) + body_offset, len - body_offset, 0, n_symbols, d_out, cap, out_len);
 }
 
-extern "C" int et_decode(et_ctx *ctx, const uint8_t *compressed, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
-    if (!ctx || !compressed || !out_len) return ET_ERR_ARG;
+namespace {
+
+// decode: source -> io_in (header parsed from the bytes as they pass) -> kernels -> io_out -> sink
+int decode_through_pipe(et_ctx *ctx, const et_io::HostEnd &src, size_t len, const et_io::HostEnd *dst, size_t cap, size_t *out_len) {
     *out_len = 0;
     if (len < 5) return fail(ctx, ET_ERR_FORMAT, "stream shorter than its header");
-    DeviceGuard guard(ctx->device);
-    size_t n_symbols = 0;
-    et_decoded_size(compressed, len, &n_symbols);
+    ET_TRY(ensure_io(ctx));
     ET_TRY(ensure(ctx, ctx->io_in, len + 16));
+    std::vector<uint8_t> head(len < HEADER_STAGE ? len : HEADER_STAGE);
+    ET_TRY(io_status(ctx, ctx->io->upload(ctx->stream, ctx->io_in.p, src, len, head.data(), head.size()), "reading the input"));
+    et_codebook cb;
+    uint64_t n_symbols = 0;
+    size_t body_offset = 0;
+    const int rc = et_parse_header(head.data(), head.size(), &cb, &n_symbols, &body_offset);
+    if (rc != ET_OK) return fail(ctx, rc, "et_parse_header");
+    if (body_offset > len) return fail(ctx, ET_ERR_FORMAT, "dictionary runs past the end of the stream");
     ET_TRY(ensure(ctx, ctx->io_out, n_symbols + 64));
-    ET_HIP(hipMemcpyAsync(ctx->io_in.p, compressed, len, hipMemcpyHostToDevice, ctx->stream));
     size_t n_out = 0;
-    ET_TRY(et_decode_device(ctx, ctx->io_in.p, len, ctx->io_out.p, n_symbols + 64, &n_out));
+    ET_TRY(et_decode_body_device(ctx, &cb, static_cast<const uint8_t *>(ctx->io_in.p) + body_offset, len - body_offset, 0, n_symbols, ctx->io_out.p,
+                                 n_symbols + 64, &n_out));
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
-    if (n_out) {
-        if (!out) return ET_ERR_ARG;
-        ET_HIP(hipMemcpyAsync(out, ctx->io_out.p, n_out, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    ET_HIP(hipStreamSynchronize(ctx->stream));
+    if (dst && n_out) ET_TRY(io_status(ctx, ctx->io->download(ctx->stream, *dst, ctx->io_out.p, n_out), "writing the output"));
+    else ET_HIP(hipStreamSynchronize(ctx->stream));
     *out_len = n_out;
     return ET_OK;
+}
+
+}  // namespace
+
+extern "C" int et_decode(et_ctx *ctx, const uint8_t *compressed, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!ctx || !compressed || !out_len) return ET_ERR_ARG;
+    DeviceGuard guard(ctx->device);
+    et_io::HostEnd src, dst;
+    src.ptr = const_cast<uint8_t *>(compressed);
+    dst.ptr = out;
+    return decode_through_pipe(ctx, src, len, out ? &dst : nullptr, out ? cap : 0, out_len);
+}
+
+extern "C" int et_decode_fd(et_ctx *ctx, int in_fd, size_t in_skip, int out_fd, size_t *in_len, size_t *out_len) {
+    if (!ctx || !in_len || !out_len || in_fd < 0) return ET_ERR_ARG;
+    *in_len = *out_len = 0;
+    uint64_t size = 0;
+    if (file_size(in_fd, &size) != 0) return fail(ctx, ET_ERR_IO, "input is not a regular file");
+    if (size < in_skip) return fail(ctx, ET_ERR_FORMAT, "file shorter than the bytes to skip");
+    DeviceGuard guard(ctx->device);
+    et_io::HostEnd src, dst;
+    src.fd = in_fd;
+    src.offset = in_skip;
+    dst.fd = out_fd;
+    *in_len = static_cast<size_t>(size - in_skip);
+    return decode_through_pipe(ctx, src, *in_len, out_fd >= 0 ? &dst : nullptr, ~static_cast<size_t>(0), out_len);
 }

@@ -34,7 +34,8 @@ typedef enum et_status {
     ET_ERR_FORMAT = 4,      /* malformed .et stream (the reference performs no validation, main.zig:199) */
     ET_ERR_HIP = 5,         /* HIP runtime failure; et_last_error() has the text */
     ET_ERR_ARG = 6,         /* null/misaligned/out-of-range argument */
-    ET_ERR_UNSUPPORTED = 7  /* stream needs a feature outside the decoder's domain (code length > 32) */
+    ET_ERR_UNSUPPORTED = 7, /* stream needs a feature outside the decoder's domain (code length > 32) */
+    ET_ERR_IO = 8           /* read/write on a file descriptor failed (et_encode_fd / et_decode_fd) */
 } et_status;
 
 /* The reference's `dictionary: [256]Code` (encode.zig:141-146) plus what its -d dump
@@ -110,6 +111,18 @@ int et_encode(et_ctx *ctx, const uint8_t *text, size_t n,
  * symbols (header field, decode.zig:36-42), or fewer when the bitstream ends first. */
 int et_decode(et_ctx *ctx, const uint8_t *compressed, size_t len,
               uint8_t *out, size_t cap, size_t *out_len);
+
+/* The same two calls on open files: the reference reads the whole input
+ * (main.zig:34-40,186) and writes the result with one writeAll (encode.zig:319,
+ * main.zig:192-197); these move the file through two pinned staging buffers in chunks
+ * (pread by a small thread pool while the previous chunk crosses PCIe; the result leaves
+ * the same way with pwrite), so host memory stays bounded whatever the file size.
+ * Regular files only (sized with fstat, positioned I/O).  out_fd < 0: code, write nothing
+ * (main.zig's -t).  et_decode_fd skips `in_skip` bytes first: 4 = main.zig:204's
+ * `text_in[4..]`.  *in_len = bytes consumed after the skip, *out_len = bytes produced.
+ * et_encode / et_decode use the same pipeline on host memory. */
+int et_encode_fd(et_ctx *ctx, int in_fd, int out_fd, size_t *in_len, size_t *out_len);
+int et_decode_fd(et_ctx *ctx, int in_fd, size_t in_skip, int out_fd, size_t *in_len, size_t *out_len);
 
 /* Code table of the ctx's most recent et_encode / et_encode_device (for the -d dump,
  * encode.zig:204-212, which the reference prints from inside encode()). */
