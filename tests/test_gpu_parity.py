@@ -364,6 +364,36 @@ def test_decode_rejects_malformed_streams(ctx):
     assert len(ctx.decode(junk)) <= n
 
 
+def test_decode_fuzzed_bodies_match_the_oracle(ctx):
+    """Bit flips, truncations and junk in the BODY of streams with intact headers, large
+    enough (several 8 KiB blocks, ragged ends) to run through the register-window
+    kernels: whatever the bits say, the GPU decode equals the oracle's intended decoder
+    (symbols whose code BEGINS before the stream's end, at most the declared count)."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        n = int(rng.integers(40_000, 400_000))
+        text = corpus.text_like(n, 500 + trial)
+        good = bytearray(O.encode(text)[4:])
+        _, _, off = E.parse_header(bytes(good))
+        kind = trial % 4
+        if kind == 0:  # scattered bit flips
+            for pos in rng.integers(off, len(good), size=50):
+                good[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:  # a run of junk in the middle
+            a = int(rng.integers(off, len(good) - 5000))
+            good[a : a + 4096] = rng.integers(0, 256, size=4096, dtype=np.uint8).tobytes()
+        elif kind == 2:  # truncated at a ragged place
+            del good[int(rng.integers(off + 1, len(good))) :]
+        else:  # all-ones / all-zeros tails (longest and shortest codes back to back)
+            good[-9000:-4500] = b"\xff" * 4500
+            good[-4500:] = b"\x00" * 4500
+        want = O.decode(bytes(good))
+        assert ctx.decode(bytes(good)) == want, f"trial {trial} kind {kind}"
+
+
 @pytest.mark.parametrize("p_common", [0.9, 0.99, 0.999])
 def test_heavily_skewed_streams(ctx, p_common):
     """One symbol dominates: 1-bit codes, up to 65536 symbols per 8 KiB block (the write
