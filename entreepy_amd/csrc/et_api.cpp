@@ -48,7 +48,6 @@ struct et_ctx {
     hipStream_t stream = nullptr;
     bool timing = false;
     uint32_t force_rpt = 0;
-    uint32_t lut_bits_max = et::DEC_LUT_BITS_DEFAULT;
     uint32_t lut_bits_write = et::DEC_LUT_BITS_WRITE;
     uint32_t step_bits = et::DEC_STEP_BITS_DEFAULT;
     std::string err;
@@ -67,7 +66,7 @@ struct et_ctx {
     uint32_t *h_enc = nullptr;      // 768: {code,len} x 256, then len x 256
     uint8_t *h_header = nullptr;    // HEADER_STAGE
     uint32_t *h_lut = nullptr;      // 1 << DEC_LUT_BITS_MAX
-    uint64_t *h_scalar = nullptr;   // 4 (flag / totals)
+    uint64_t *h_scalar = nullptr;   // 16: [1] a total, [2..3] flags (range decode), [4..11] the body decode's copy of flag[0..15]
 
     // link between et_histogram_device and et_encode_body_device
     const void *hist_text = nullptr;
@@ -76,6 +75,7 @@ struct et_ctx {
     bool hist_on_host = false;  // h_hist holds the counts of hist_text
 
     hipEvent_t ev[12] = {};  // 0..5: encode calls, EV_DEC + 0..5: decode calls
+    hipEvent_t ev_flags = nullptr;  // body decode: the sweep flags and the symbol total have reached the host
     et_timings tm_enc = {}, tm_dec = {};
     // A full encode / body decode with timing on leaves its event arithmetic for the first
     // et_last_timings[_of] call (which waits for the call's last event): the call itself
@@ -285,10 +285,6 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     et_ctx *ctx = new (std::nothrow) et_ctx();
     if (!ctx) return ET_ERR_NOMEM;
     ctx->device = device;
-    if (const char *env = std::getenv("ET_DEC_LUT_BITS")) {  // tuning knob: first-level decode table size
-        const long v = std::strtol(env, nullptr, 10);
-        if (v >= 8 && v <= static_cast<long>(et::DEC_LUT_BITS_MAX)) ctx->lut_bits_max = static_cast<uint32_t>(v);
-    }
     if (const char *env = std::getenv("ET_DEC_STEP_BITS")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 8 && v <= static_cast<long>(et::DEC_STEP_BITS_MAX)) ctx->step_bits = static_cast<uint32_t>(v);
@@ -308,8 +304,9 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 768 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), DEC_TABLES_BYTES) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 4 * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 16 * sizeof(uint64_t)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_flags, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         et_ctx_destroy(ctx);
         return ET_ERR_HIP;
@@ -335,6 +332,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->ev_flags) (void)hipEventDestroy(ctx->ev_flags);
     if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
     if (ctx->side.fork) (void)hipEventDestroy(ctx->side.fork);
     if (ctx->side.join) (void)hipEventDestroy(ctx->side.join);
@@ -789,10 +787,15 @@ uint32_t build_write_step_table(const et_codebook *cb, uint32_t bits_max, uint32
     return k;
 }
 
-// Build both table sets on the host and upload them: the sync/count sweeps (index
-// lut_bits_max, DEC_SYNC_SYMS symbols per entry) and the write kernel (index lut_bits_write,
-// DEC_WRITE_SYMS symbols; its own second-level tables and long list, since those depend on
-// the index width).
+// Build the decode tables on the host and upload them (one pinned block, one device block,
+// one copy): the step tables of the register-window kernels (k_dec_sync_reg: index
+// step_bits, symbol-free; k_dec_write_reg: index lut_bits_write, two symbols) and ONE set of
+// first/second-level tables + long list in the older format (index lut_bits_write, two
+// symbols per entry) for the LDS-window kernels -- first/last blocks, ranges, the exhaustive
+// path -- and the slow path of the step walks.  (A three-symbol set for the counting kernels
+// used to be built as well: 12 us of host time per call for kernels that now see three
+// blocks of a stream; near-fixed-length codes, the exhaustive path's domain, rarely fit two
+// codes in an index anyway.)
 int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *tb_out, et::DecodeTables *tb_write_out) {
     // one pinned block, one device block, one upload: [first-level x 2 | long lists | second-level (+ lengths) x 2]
     ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
@@ -803,9 +806,10 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     uint32_t *h_long = ctx->h_lut + (2u << et::DEC_LUT_BITS_MAX), *h_long_w = h_long + 512;
     uint16_t *h_sub = reinterpret_cast<uint16_t *>(h_long + 1024);
     uint16_t *h_sub_w = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(h_sub) + SUB_TABLE_BYTES);
-    build_decode_tables(cb, ctx->lut_bits_max, et::DEC_SYNC_SYMS, ctx->h_lut, h_long, h_sub, &ht);
+    (void)h_long;
+    (void)h_sub;
     build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
-    std::memcpy(reinterpret_cast<uint8_t *>(h_sub) + SUB_TABLE_ONLY, cb->length, 256);
+    ht = hw;
     std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
     uint32_t *h_steps = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->h_lut) + DEC_STEPS_OFFSET);
     uint32_t step_sub_bits = 0, n_step_sub = 0;
@@ -819,10 +823,11 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     const uint32_t *d_lut = static_cast<const uint32_t *>(ctx->lut.p);
     const uint32_t *d_long = d_lut + (2u << et::DEC_LUT_BITS_MAX);
     const uint8_t *subt = reinterpret_cast<const uint8_t *>(d_long + 1024);
-    *tb_out = et::DecodeTables{d_lut, d_long, reinterpret_cast<const uint16_t *>(subt), subt + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits,
+    *tb_out = et::DecodeTables{d_lut + (1u << et::DEC_LUT_BITS_MAX), d_long + 512, reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES),
+                               subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits,
                                ht.n_sub, reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET), step_bits,
                                step_sub_bits, n_step_sub};
-    *tb_write_out = et::DecodeTables{tb_out->lut + (1u << et::DEC_LUT_BITS_MAX), tb_out->longc + 512,
+    *tb_write_out = et::DecodeTables{d_lut + (1u << et::DEC_LUT_BITS_MAX), d_long + 512,
                                      reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES), subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
                                      hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub,
                                      reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET + step_bytes), wstep_bits,
@@ -874,26 +879,33 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     static const bool use_side = [] { const char *e = std::getenv("ET_DEC_SIDE"); return !(e && e[0] == '0'); }();  // A/B switch
     const et::SideLane *side = use_side ? &ctx->side : nullptr;
 
-    // D1..D3.  Sweep 0 runs in and repairs inside each block; sweeps 1 and 2 repair across
-    // blocks (a sweep that changes nothing ends the search: on text sweep 1 fixes ~0.4 %
-    // of the block boundaries and sweep 2 finds nothing).  Everything up to the write
-    // kernel is enqueued without waiting; the flags and the symbol total are read back
-    // in ONE synchronisation, and only if they say so (blocks that do not synchronise ->
-    // exhaustive path; sweep 2 still changed something -> more sweeps) is the tail redone.
+    // D1..D3.  Sweep 0 runs in and repairs inside each block; sweep 1 repairs across blocks
+    // (on text ~0.4 % of the block boundaries); the scan that follows also verifies that
+    // every block now starts where its predecessor ends (the "sweep that changes nothing").
+    // Everything up to the write kernel is enqueued without waiting; the flags and the
+    // symbol total come back in ONE read and ONE synchronisation, and only if they say so
+    // (blocks that do not synchronise -> exhaustive path; verification failed -> more
+    // sweeps) is the tail redone.  Device words: flag[0] sweep-1 changed, [1] blocks that
+    // gave up, [2] verification failed, [4] / [5] tickets of D1 / D3, [8] worklist count,
+    // [12..13] symbol total.
     uint32_t iters = 0;
     ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
     unsigned long long *group_sum = static_cast<unsigned long long *>(ctx->group_sum.p);
-    uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 2);  // [0] sweep-1 changed, [1] unconverged blocks, [2] sweep-2 changed
+    uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 4);  // host copy of flag[0..15]
     const bool can_speculate = cap >= n_symbols;
-    bool wrote = false;
-    auto scan_and_total = [&]() -> int {
-        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off);
+    bool wrote = false, write_ticket_zero = false;
+    auto scan_and_total = [&](bool verify) -> int {
+        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
+                            verify ? sub_state : nullptr, blk_exit, flag + 2);
         ET_HIP(hipGetLastError());
-        ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipMemcpyAsync(h_flags, flag, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
         return ET_OK;
     };
     auto write_symbols = [&](uint64_t clamp) -> int {
-        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 4, side);
+        et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
+                             write_ticket_zero);
+        write_ticket_zero = false;
         ET_HIP(hipGetLastError());
         return ET_OK;
     };
@@ -902,24 +914,22 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     bool more_sweeps = false;
     if (!exhaustive) {
         ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
+        write_ticket_zero = true;
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
-                            et::DEC_HAVE_START, nullptr, nullptr, side);
+                            et::DEC_HAVE_START, nullptr, nullptr, side, true);
         record(ctx, EV_DEC + 5);
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
-                            et::DEC_HAVE_START, worklist, flag + 8);
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 2, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag + 2, flag + 4,
-                            et::DEC_HAVE_START, worklist, flag + 9);
+                            et::DEC_HAVE_START, worklist, flag + 8, side);
         ET_HIP(hipGetLastError());
-        iters = 3;
+        iters = 3;  // run-in sweep, repair sweep, verification
         record(ctx, EV_DEC + 1);
-        ET_TRY(scan_and_total());
-        ET_HIP(hipMemcpyAsync(h_flags, flag, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_TRY(scan_and_total(true));
         record(ctx, EV_DEC + 2);
         if (can_speculate) {
             ET_TRY(write_symbols(n_symbols));
             wrote = true;
         }
-        ET_HIP(hipStreamSynchronize(ctx->stream));
+        ET_HIP(hipEventSynchronize(ctx->ev_flags));  // not the stream: the write kernel keeps running while the caller moves on
         exhaustive = static_cast<uint64_t>(h_flags[1]) * 64 > n_blocks;
         more_sweeps = !exhaustive && h_flags[2] != 0;
         if (exhaustive || more_sweeps) wrote = false;  // the speculative output is void
@@ -953,11 +963,11 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     }
     if (exhaustive || more_sweeps) {
         record(ctx, EV_DEC + 1);
-        ET_TRY(scan_and_total());
+        ET_TRY(scan_and_total(false));
         record(ctx, EV_DEC + 2);
-        ET_HIP(hipStreamSynchronize(ctx->stream));
+        ET_HIP(hipEventSynchronize(ctx->ev_flags));
     }
-    const uint64_t decodable = ctx->h_scalar[1];
+    const uint64_t decodable = static_cast<uint64_t>(h_flags[12]) | (static_cast<uint64_t>(h_flags[13]) << 32);
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
     if (n_out && !wrote) ET_TRY(write_symbols(n_out));
@@ -1076,7 +1086,8 @@ extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t le
     DeviceGuard guard(ctx->device);
     // The header and dictionary (<= 4627 bytes after the 4 stripped ones) are parsed on the host.
     const size_t head = len < HEADER_STAGE ? len : HEADER_STAGE;
-    ET_HIP(hipStreamSynchronize(ctx->stream));  // the pinned header stage may still feed an earlier encode
+    // (no wait before the copy: an earlier encode's upload FROM the pinned header stage is
+    // ahead of this copy INTO it on the same stream)
     uint8_t *hdr_data = ctx->h_header;
     ET_HIP(hipMemcpyAsync(hdr_data, d_compressed, head, hipMemcpyDeviceToHost, ctx->stream));
     ET_HIP(hipStreamSynchronize(ctx->stream));

@@ -42,7 +42,6 @@ constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GU
 constexpr uint32_t DEC_SDATA_WORDS = (DEC_STAGED_WORDS + (DEC_STAGED_WORDS >> 5) + 4) & ~3u;  // 1 pad word per 32
 constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: at most 4096 x u32 in LDS
 constexpr uint32_t DEC_LUT_BITS_WRITE = 11;                    // write kernels: measured 10 / 11 / 12 -> 0.65 / 0.60 / 0.68 ms at 1 GiB
-constexpr uint32_t DEC_LUT_BITS_DEFAULT = 11;                  // measured best on text (K = 10..11 tie, 12 and 9 slower)
 // first-level table entry (u32), indexed by the next lut_bits bits: bytes 0..2 = up to
 // three symbols whose codes all fit in the index, bits 24..27 = total length of those
 // codes, bits 28..29 = how many (0: the first code is longer than the table, or no code
@@ -50,9 +49,8 @@ constexpr uint32_t DEC_LUT_BITS_DEFAULT = 11;                  // measured best 
 // second-level table of 1 << sub_bits u16 entries ((len << 8) | sym, 0 = not here)
 // indexed by the sub_bits bits that follow the first lut_bits.
 constexpr uint32_t LUT_LEN_SHIFT = 24, LUT_N_SHIFT = 28, LUT_SUB_SHIFT = 30;
-// symbols per entry: the sync/count sweeps take three; the write kernel two (a third LDS
-// byte store per step costs it more than the saved steps)
-constexpr uint32_t DEC_SYNC_SYMS = 3, DEC_WRITE_SYMS = 2;
+// symbols per entry of the older-format tables: two (k_dec_write stores at most two per step)
+constexpr uint32_t DEC_WRITE_SYMS = 2;
 constexpr uint32_t DEC_SUB_BITS_MAX = 8, DEC_SUB_TABLES_MAX = 16;
 constexpr uint32_t DEC_STAGE_BYTES = 16384;                    // LDS staging of decoded symbols
 
@@ -109,15 +107,18 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket,
-                     uint32_t flags = DEC_HAVE_START, uint32_t *worklist = nullptr, uint32_t *n_work = nullptr, const SideLane *side = nullptr);
+                     uint32_t flags = DEC_HAVE_START, uint32_t *worklist = nullptr, uint32_t *n_work = nullptr, const SideLane *side = nullptr,
+                     bool ticket_is_zero = false);
 void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                            const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
                            uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,
                            uint32_t *blk_count);
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
-                     unsigned long long *blk_off);
+                     unsigned long long *blk_off, unsigned long long *total_copy = nullptr, const uint32_t *verify_state = nullptr,
+                     const uint32_t *verify_exit = nullptr, uint32_t *verify_flag = nullptr);
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
-                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr);
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr,
+                      bool ticket_is_zero = false);
 
 }  // namespace et

@@ -128,10 +128,13 @@ __device__ __forceinline__ Chunk load_chunk_in_tile(const uint8_t *__restrict__ 
 // cycles per wave-instruction, ~4.9 TB/s chip-wide), not occupancy.
 // Counters are u32 (a tile is at most 64 KiB); tile totals go out as u32,
 // workgroup totals as u64.
+#ifndef ET_HIST_ATOMIC_TOTAL
+#define ET_HIST_ATOMIC_TOTAL 0  // measured: K1 itself 27 us slower with the atomics in its tail, the reduce kernel costs 13 + launch
+#endif
 __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
                                                       uint32_t rounds_per_tile, uint32_t n_tiles,
                                                       uint32_t *__restrict__ tile_hist,
-                                                      unsigned long long *__restrict__ block_hist) {
+                                                      unsigned long long *__restrict__ block_hist, unsigned long long *__restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint32_t sh[256 * 32];
     const int tid = threadIdx.x;
     for (int i = tid; i < 256 * 32; i += BLOCK) sh[i] = 0;
@@ -187,7 +190,13 @@ __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict_
         acc += total;
         __syncthreads();
     }
+#if ET_HIST_ATOMIC_TOTAL
+    // Workgroups finish at different times, so their 256 atomics each (2048 x 256 on 256
+    // addresses) hide under the kernel's tail; a separate reduce kernel cost 13 us + a launch.
+    if (acc) atomicAdd(hist + tid, acc);
+#else
     block_hist[static_cast<uint64_t>(blockIdx.x) * 256 + tid] = acc;
+#endif
 }
 
 // Column sums of block_hist[n_rows][256] into hist[256] (zeroed beforehand).
@@ -225,12 +234,17 @@ __global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict_
 // total and, for the encoder, zeroes every 32-bit output word that holds a tile
 // boundary: those are the only words two workgroups of K4 may share, and K4 merges
 // into them with atomicOr.
+// verify_state / verify_exit / verify_flag (decode only, else null): the scan's thread i also
+// checks that block i's first subsequence started where block i-1 ended (the "sweep that
+// changes nothing" of the synchronisation, folded in here) and raises *verify_flag if not.
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out,
-                                                     unsigned long long *__restrict__ group_sum) {
+                                                     unsigned long long *__restrict__ group_sum, const uint32_t *__restrict__ verify_state,
+                                                     const uint32_t *__restrict__ verify_exit, uint32_t *__restrict__ verify_flag) {
     __shared__ unsigned long long wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i = blockIdx.x * 1024 + tid;
+    if (verify_state && i > 0 && i < n && (verify_state[static_cast<uint64_t>(i) * BLOCK] & 0xffu) != verify_exit[i - 1]) *verify_flag = 1;
     const unsigned long long x = (i < n) ? static_cast<unsigned long long>(in[i]) : 0ull;
     const unsigned long long inc = wave_inclusive_scan64(x);
     if (lane == 63) wsum[wave] = inc;
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, u
 
 __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__restrict__ out, uint32_t n,
                                                       const unsigned long long *__restrict__ group_sum, unsigned long long base,
-                                                      uint32_t *__restrict__ zero_words) {
+                                                      uint32_t *__restrict__ zero_words, unsigned long long *__restrict__ total_copy) {
     __shared__ unsigned long long wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
@@ -264,6 +278,7 @@ __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__rest
     if (g == gridDim.x - 1 && tid == 0) {
         const unsigned long long total = prefix + group_sum[g];
         out[n] = total;
+        if (total_copy) *total_copy = total;  // next to the sweep flags: one read-back for the host
         if (zero_words) zero_words[total >> 5] = 0;
     }
 }
@@ -1727,9 +1742,11 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist) {
     const uint32_t grid = n_tiles < MAX_GRID ? n_tiles : MAX_GRID;  // over-subscribed on purpose: an exact-residency grid measured slower for K1
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
-    hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist);
+    hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
+#if !ET_HIST_ATOMIC_TOTAL
     const uint32_t rgrid = grid < 512 ? grid : 512;
     hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
+#endif
 }
 
 
@@ -1740,8 +1757,8 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
     if (grid > MAX_GRID) grid = MAX_GRID;
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
     const uint32_t groups = (n_tiles + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32);
+    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr));
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr));
 }
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
@@ -1784,7 +1801,7 @@ static void join_special(const SideLane *side, hipStream_t stream) {
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket, uint32_t flags,
-                     uint32_t *worklist, uint32_t *n_work, const SideLane *side) {
+                     uint32_t *worklist, uint32_t *n_work, const SideLane *side, bool ticket_is_zero) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
@@ -1793,7 +1810,7 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
         static const uint32_t chunk = [] { const char *e = getenv("ET_SYNC_REG_TICKET"); return e ? static_cast<uint32_t>(atoi(e)) : 4u; }();  // blocks per ticket (0: one workgroup per block); measured 0/4/8/16
         const bool ticketed = chunk > 0;
         if (iter == 0 && ticketed) {
-            (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+            if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
             const hipStream_t special = fork_special(side, stream);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
             hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
@@ -1808,6 +1825,7 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
             } else {
                 hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             }
+            // (not on the side lane: the fork/join events cost more than these ~5 us)
             hipLaunchKernelGGL(k_dec_sync<false>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         }
         return;
@@ -1837,19 +1855,20 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
 }
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
-                     unsigned long long *blk_off) {
+                     unsigned long long *blk_off, unsigned long long *total_copy, const uint32_t *verify_state, const uint32_t *verify_exit,
+                     uint32_t *verify_flag) {
     const uint32_t groups = (n_blocks + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr));
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag);
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy);
 }
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
-                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side) {
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
     const size_t smem = decode_smem_bytes(tb, true, false);
-    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+    if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (use_reg_kernels(n_blocks)) {
         const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
         const hipStream_t special = fork_special(side, stream);

@@ -132,7 +132,9 @@ int et_last_codebook(const et_ctx *ctx, et_codebook *out);
 int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols);
 
 /* Same two calls with input and output resident in HBM (benchmarks, pipelines).
- * d_out must hold et_encode_bound(n) bytes / n_symbols (+16 slack) bytes. */
+ * d_out must hold et_encode_bound(n) bytes / n_symbols (+16 slack) bytes.  Both are
+ * stream-ordered: *out_len is final on return, the bytes in d_out are complete once the
+ * ctx's stream has drained (enqueue consumers on it, or synchronise it). */
 int et_encode_device(et_ctx *ctx, const void *d_text, size_t n,
                      void *d_out, size_t cap, size_t *out_len);
 int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t len,
