@@ -36,7 +36,7 @@ constexpr size_t SUB_TABLE_ONLY = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) <
 constexpr size_t SUB_TABLE_BYTES = SUB_TABLE_ONLY + 256;
 constexpr size_t DEC_STEPS_OFFSET = (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2 + 1024 * sizeof(uint32_t) + 2 * SUB_TABLE_BYTES;  // multiple of 64
 constexpr size_t DEC_TABLES_BYTES = DEC_STEPS_OFFSET + (sizeof(uint32_t) << et::DEC_STEP_BITS_MAX) + (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) +
-                                    2 * (et::DEC_STEP_SUB_WORDS + 4) * sizeof(uint32_t);
+                                    2 * (et::DEC_STEP_SUB_WORDS + 4) * sizeof(uint32_t) + 2 * sizeof(et::DecodeTables) + 64;
 //  // the per-symbol code lengths ride behind the tables  // + slack for 16-byte rounded copies
 
 }  // namespace
@@ -819,19 +819,27 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     uint32_t wstep_sub_bits = 0, n_wstep_sub = 0;
     const uint32_t wstep_bits = build_write_step_table(cb, ctx->lut_bits_write, h_wsteps, &wstep_sub_bits, &n_wstep_sub);
     const size_t wstep_bytes = (((static_cast<size_t>(1) << wstep_bits) + (static_cast<size_t>(n_wstep_sub) << wstep_sub_bits) + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t);
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, DEC_STEPS_OFFSET + step_bytes + wstep_bytes, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t *d_lut = static_cast<const uint32_t *>(ctx->lut.p);
     const uint32_t *d_long = d_lut + (2u << et::DEC_LUT_BITS_MAX);
     const uint8_t *subt = reinterpret_cast<const uint8_t *>(d_long + 1024);
     *tb_out = et::DecodeTables{d_lut + (1u << et::DEC_LUT_BITS_MAX), d_long + 512, reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES),
                                subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits,
                                ht.n_sub, reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET), step_bits,
-                               step_sub_bits, n_step_sub};
+                               step_sub_bits, n_step_sub, nullptr};
     *tb_write_out = et::DecodeTables{d_lut + (1u << et::DEC_LUT_BITS_MAX), d_long + 512,
                                      reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES), subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY,
                                      hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub,
                                      reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET + step_bytes), wstep_bits,
-                                     wstep_sub_bits, n_wstep_sub};
+                                     wstep_sub_bits, n_wstep_sub, nullptr};
+    // device copies of the two structs ride behind the tables (slow path of the step walks)
+    const size_t structs_at = DEC_STEPS_OFFSET + step_bytes + wstep_bytes;
+    const et::DecodeTables *d_structs = reinterpret_cast<const et::DecodeTables *>(reinterpret_cast<const uint8_t *>(d_lut) + structs_at);
+    tb_out->dev_copy = d_structs;
+    tb_write_out->dev_copy = d_structs + 1;
+    et::DecodeTables *h_structs = reinterpret_cast<et::DecodeTables *>(reinterpret_cast<uint8_t *>(ctx->h_lut) + structs_at);
+    h_structs[0] = *tb_out;
+    h_structs[1] = *tb_write_out;
+    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, structs_at + 2 * sizeof(et::DecodeTables), hipMemcpyHostToDevice, ctx->stream));
     return ET_OK;
 }
 

@@ -69,6 +69,7 @@ struct DecodeTables {
     uint32_t step_bits;
     uint32_t step_sub_bits;
     uint32_t n_step_sub;
+    const DecodeTables *dev_copy;  // this struct in device memory (slow path of the step walks), or null
 };
 
 // Step table of k_dec_sync_reg (no symbols, only how far a lookup moves the walk).  The

@@ -1209,18 +1209,50 @@ __host__ __device__ __forceinline__ uint32_t step_table_words(const DecodeTables
     return ((1u << tb.step_bits) + (tb.n_step_sub << tb.step_sub_bits) + 3u) & ~3u;
 }
 
-// The synchronisation walk over a lane's registers: counts, keeps no symbols.  `steps` is
-// the step table in LDS (et_kernels.h STEP_*).  Bits are counted from A = 0 at 32 bits
-// before W[0]: the run-in starts at A = 32, the subsequence covers A in [160, 416).
-// Word iteration j (register pair W[j-1], W[j]) owns A in (32 j, 32 (j + 1)]; with
-// F = low half of X = STEP_BIAS - A that is F >= STEP_BIAS - 32 (j + 1), a 16-bit compare
-// against a constant, and v_alignbit_b32's shift (-A mod 32) is X's low five bits as they
-// are.  A step is: alignbit, shift, address, LDS read, add, compare.
+// Kernel-argument form of a step table (DecodeTables::steps ...): the table in global
+// memory, its size in words (both levels, multiple of 4), and the device copy of the
+// DecodeTables for the slow path.
+struct StepTableArgs {
+    const uint32_t *table;
+    const DecodeTables *slow;
+    uint32_t words, step_bits, sub_bits;
+};
+static inline StepTableArgs step_table_args(const DecodeTables &tb) {
+    return StepTableArgs{tb.steps, tb.dev_copy, step_table_words(tb), tb.step_bits, tb.step_sub_bits};
+}
+
+// What the step walks need besides their LDS tables: by value only what a step touches;
+// the tables of the slow path stay behind a pointer to a device copy of the DecodeTables
+// (fewer SGPRs live across the walk: the kernels are SGPR-limited to 7 wavefronts per SIMD
+// otherwise, and 8 is worth 9 % in k_dec_sync_reg).
+struct StepWalk {
+    const uint32_t *steps;      // LDS: first level, second level behind it
+    const DecodeTables *slow;   // global memory
+    uint32_t idx_shift, step_bits, sub_bits, multi_floor;
+};
+
+#ifndef ET_SLOW_INLINE
+#define ET_SLOW_INLINE __attribute__((noinline))
+#endif
+__device__ ET_SLOW_INLINE uint32_t decode_one_slow_p(const DecodeTables *tb, uint32_t window) {
+    const uint32_t bits = tb->lut_bits | (tb->sub_bits << 8);
+    const uint32_t e = tb->lut[window >> (32 - tb->lut_bits)];
+    if ((e >> LUT_N_SHIFT) & 3u) return (static_cast<uint32_t>(tb->sym_len[e & 0xffu]) << 8) | (e & 0xffu);
+    return long_code_flat(tb->sub, tb->longc, tb->n_long, bits, e, window);
+}
+
+// The synchronisation walk over a lane's registers: counts, keeps no symbols (step table:
+// et_kernels.h STEP_*).  Word iteration j works on the register pair (W[j-1], W[j]); the
+// walk's position is kept RELATIVE TO THAT PAIR: the low half of X is G = 96 - sh, sh =
+// bits from the first bit of W[j-1].  In the word <=> sh <= 32 <=> G >= 64; after the word
+// G += 32; a lane thrown out by the escape pseudo-step (64 bits) has G < 32, a regular
+// exit 32 <= G < 64: every word compares against the same two inline constants, and
+// v_alignbit_b32's shift (-sh mod 32) is G's low five bits as they are.  A step is:
+// alignbit, shift, address, LDS read, add, and, compare.
 template <bool WARM>
-__device__ __forceinline__ SubResult walk_steps(const uint32_t *steps, const DecodeTables &tb, const uint32_t (&W)[RW_WORDS], uint32_t start_rel,
-                                                uint32_t (&ck)[8]) {
-    const uint32_t idx_shift = 32 - tb.step_bits;
-    const uint32_t *ssub = steps + (1u << tb.step_bits);
+__device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32_t (&W)[RW_WORDS], uint32_t start_rel, uint32_t (&ck)[8]) {
+    const uint32_t *steps = sw.steps;
+    const uint32_t idx_shift = sw.idx_shift;
     uint32_t X, e = 0;
     SubResult res;
     res.start_rel = start_rel;
@@ -1231,69 +1263,69 @@ __device__ __forceinline__ SubResult walk_steps(const uint32_t *steps, const Dec
     {                                                                                                                  \
         const uint32_t w_ = __builtin_amdgcn_alignbit(hi_, lo_, X), t_ = e >> 28;                                      \
         uint32_t add_ = 0;                                                                                             \
-        if (t_) add_ = ssub[((t_ - 1) << tb.step_sub_bits) | ((w_ << tb.step_bits) >> (32 - tb.step_sub_bits))];       \
+        if (t_) add_ = steps[(1u << sw.step_bits) + (((t_ - 1) << sw.sub_bits) | ((w_ << sw.step_bits) >> (32 - sw.sub_bits)))]; \
         if (add_ == 0) {                                                                                               \
-            const uint32_t hit_ = decode_one_slow(tb.lut, tb.sym_len, tb.sub, tb.longc, tb.n_long, tb.lut_bits | (tb.sub_bits << 8), w_); \
+            const uint32_t hit_ = decode_one_slow_p(sw.slow, w_);                                                      \
             add_ = hit_ ? (1u << 16) - (hit_ >> 8) : ~0u; /* no code: one bit on, no symbol */                         \
         }                                                                                                              \
         X += add_;                                                                                                     \
     }
-// word j, all of whose step_bits windows end before the stretch's limit.  A lane leaves the
-// inner loop at A in (32 (j+1), 32 (j+2)] -- or, after the escape pseudo-step, beyond that
-#define ET_SW_WORD(j_, hi_, lo_)                                                      \
+// a word all of whose step_bits windows end before the stretch's limit
+#define ET_SW_WORD(hi_, lo_)                                                          \
     for (;;) {                                                                        \
-        while (ET_F >= STEP_BIAS - 32 * ((j_) + 1)) ET_SW_STEP(hi_, lo_)              \
-        if (ET_F >= STEP_BIAS - 32 * ((j_) + 2)) break;                               \
-        X -= STEP_ESCAPE;                                                             \
-        ET_SW_SLOW(hi_, lo_)                                                          \
-    }
-// the word that ends at the stretch's limit LIM_ (in A): whole-index steps while
-// step_bits bits are left before the limit, then single codewords
-#define ET_SW_LAST_WORD(hi_, lo_, LIM_)                                               \
-    for (;;) {                                                                        \
-        while (ET_F >= multi_floor - (LIM_)) ET_SW_STEP(hi_, lo_)                     \
-        if (ET_F >= STEP_BIAS - (LIM_) - 32) break;                                   \
+        while (ET_F >= 64) ET_SW_STEP(hi_, lo_)                                       \
+        if (ET_F >= 32) break;                                                        \
         X -= STEP_ESCAPE;                                                             \
         ET_SW_SLOW(hi_, lo_)                                                          \
     }                                                                                 \
-    while (ET_F > STEP_BIAS - (LIM_)) {                                               \
+    X += 32;
+// the word at whose END the stretch ends: whole-index steps while step_bits bits are left
+// before the limit, then single codewords.  Leaves G alone: 64 - G is how far the last
+// codeword reached past the limit.
+#define ET_SW_LAST_WORD(hi_, lo_)                                                     \
+    for (;;) {                                                                        \
+        while (ET_F >= sw.multi_floor) ET_SW_STEP(hi_, lo_)                           \
+        if (ET_F >= 32) break;                                                        \
+        X -= STEP_ESCAPE;                                                             \
+        ET_SW_SLOW(hi_, lo_)                                                          \
+    }                                                                                 \
+    while (ET_F > 64) {                                                               \
         e = steps[__builtin_amdgcn_alignbit(hi_, lo_, X) >> idx_shift];               \
         if (static_cast<uint16_t>(e) != static_cast<uint16_t>(STEP_ESCAPE)) X += (1u << 16) - (e >> 28); \
         else ET_SW_SLOW(hi_, lo_)                                                     \
     }
-    const uint32_t multi_floor = STEP_BIAS + tb.step_bits;
 
     if (WARM) {
-        X = STEP_BIAS - 32 * (5 - RW_WARM_WORDS);  // the run-in starts with word W[4 - RW_WARM_WORDS]
-        if (RW_WARM_WORDS >= 4) ET_SW_WORD(0, 0u, W[0])
-        if (RW_WARM_WORDS >= 3) ET_SW_WORD(1, W[0], W[1])
-        if (RW_WARM_WORDS >= 2) ET_SW_WORD(2, W[1], W[2])
-        ET_SW_WORD(3, W[2], W[3])
-        ET_SW_LAST_WORD(W[3], W[4], 160)
+        X = 64;  // first bit of the run-in's first word
+        if (RW_WARM_WORDS >= 4) ET_SW_WORD(0u, W[0])
+        if (RW_WARM_WORDS >= 3) ET_SW_WORD(W[0], W[1])
+        if (RW_WARM_WORDS >= 2) ET_SW_WORD(W[1], W[2])
+        ET_SW_WORD(W[2], W[3])
+        ET_SW_LAST_WORD(W[3], W[4])
         X &= 0xffffu;  // nothing counted so far
-        res.start_rel = STEP_BIAS - 160 - X;
+        res.start_rel = 64 - X;  // in [0, 31]; G is already what the next word wants
     } else {
-        X = STEP_BIAS - 160 - start_rel;
+        X = 64 - start_rel;
     }
     // ck[]: the state after each of the subsequence's first eight words (rewalk_steps)
-    ET_SW_WORD(4, W[3], W[4])  // only lanes that start at bit 0
+    ET_SW_WORD(W[3], W[4])  // only lanes that start at bit 0
     ck[0] = X;
-    ET_SW_WORD(5, W[4], W[5])
+    ET_SW_WORD(W[4], W[5])
     ck[1] = X;
-    ET_SW_WORD(6, W[5], W[6])
+    ET_SW_WORD(W[5], W[6])
     ck[2] = X;
-    ET_SW_WORD(7, W[6], W[7])
+    ET_SW_WORD(W[6], W[7])
     ck[3] = X;
-    ET_SW_WORD(8, W[7], W[8])
+    ET_SW_WORD(W[7], W[8])
     ck[4] = X;
-    ET_SW_WORD(9, W[8], W[9])
+    ET_SW_WORD(W[8], W[9])
     ck[5] = X;
-    ET_SW_WORD(10, W[9], W[10])
+    ET_SW_WORD(W[9], W[10])
     ck[6] = X;
-    ET_SW_WORD(11, W[10], W[11])
+    ET_SW_WORD(W[10], W[11])
     ck[7] = X;
-    ET_SW_LAST_WORD(W[11], W[12], 416)
-    res.exit_rel = STEP_BIAS - 416 - (X & 0xffffu);
+    ET_SW_LAST_WORD(W[11], W[12])
+    res.exit_rel = 64 - (X & 0xffffu);
     res.count = (X >> 16) & 0xfffu;
     return res;
 }
@@ -1303,42 +1335,41 @@ __device__ __forceinline__ SubResult walk_steps(const uint32_t *steps, const Dec
 // where the old one stood at the same word boundary -- from there on they are the same
 // walk, and only the symbol count has to be carried over.  (The wavefront skips the words
 // in which none of its lanes is still walking.)
-__device__ __forceinline__ SubResult rewalk_steps(const uint32_t *steps, const DecodeTables &tb, const uint32_t (&W)[RW_WORDS], uint32_t start_rel,
-                                                  uint32_t (&ck)[8], uint32_t old_exit, uint32_t old_count) {
-    const uint32_t idx_shift = 32 - tb.step_bits;
-    const uint32_t *ssub = steps + (1u << tb.step_bits);
-    const uint32_t multi_floor = STEP_BIAS + tb.step_bits;
-    uint32_t X = STEP_BIAS - 160 - start_rel, e = 0;
+__device__ __forceinline__ SubResult rewalk_steps(const StepWalk &sw, const uint32_t (&W)[RW_WORDS], uint32_t start_rel, uint32_t (&ck)[8],
+                                                  uint32_t old_exit, uint32_t old_count) {
+    const uint32_t *steps = sw.steps;
+    const uint32_t idx_shift = sw.idx_shift;
+    uint32_t X = 64 - start_rel, e = 0;
     SubResult res;
     res.start_rel = start_rel;
     res.exit_rel = old_exit;
     res.count = 0;
     bool merged = false;
     uint32_t shift = 0;
-#define ET_RW_CHECK(j_, hi_, lo_)                                                            \
+#define ET_RW_CHECK(c_, hi_, lo_)                                                            \
     if (!merged) {                                                                           \
-        ET_SW_WORD(j_, hi_, lo_)                                                             \
-        if (static_cast<uint16_t>(X) == static_cast<uint16_t>(ck[(j_) - 4])) {               \
+        ET_SW_WORD(hi_, lo_)                                                                 \
+        if (static_cast<uint16_t>(X) == static_cast<uint16_t>(ck[c_])) {                     \
             merged = true;                                                                   \
-            res.count = (old_count + (X >> 16) - (ck[(j_) - 4] >> 16)) & 0xfffu;             \
+            res.count = (old_count + (X >> 16) - (ck[c_] >> 16)) & 0xfffu;                   \
             shift = (res.count - old_count) << 16;                                           \
         }                                                                                    \
-        ck[(j_) - 4] = X;                                                                    \
+        ck[c_] = X;                                                                          \
     } else {                                                                                 \
-        ck[(j_) - 4] += shift; /* same walk from here on, other count before it */           \
+        ck[c_] += shift; /* same walk from here on, other count before it */                 \
     }
-    ET_RW_CHECK(4, W[3], W[4])
-    ET_RW_CHECK(5, W[4], W[5])
-    ET_RW_CHECK(6, W[5], W[6])
-    ET_RW_CHECK(7, W[6], W[7])
-    ET_RW_CHECK(8, W[7], W[8])
-    ET_RW_CHECK(9, W[8], W[9])
-    ET_RW_CHECK(10, W[9], W[10])
-    ET_RW_CHECK(11, W[10], W[11])
+    ET_RW_CHECK(0, W[3], W[4])
+    ET_RW_CHECK(1, W[4], W[5])
+    ET_RW_CHECK(2, W[5], W[6])
+    ET_RW_CHECK(3, W[6], W[7])
+    ET_RW_CHECK(4, W[7], W[8])
+    ET_RW_CHECK(5, W[8], W[9])
+    ET_RW_CHECK(6, W[9], W[10])
+    ET_RW_CHECK(7, W[10], W[11])
 #undef ET_RW_CHECK
     if (!merged) {
-        ET_SW_LAST_WORD(W[11], W[12], 416)
-        res.exit_rel = STEP_BIAS - 416 - (X & 0xffffu);
+        ET_SW_LAST_WORD(W[11], W[12])
+        res.exit_rel = 64 - (X & 0xffffu);
         res.count = (X >> 16) & 0xfffu;
     }
     return res;
@@ -1362,15 +1393,36 @@ __device__ __forceinline__ void load_window(uint32_t (&W)[RW_WORDS], const uint3
 
 // D1 for interior blocks; same protocol and state as k_dec_sync (which keeps the special
 // blocks: the stream's first block and the one or two it ends in).
+// Occupancy targets handed to the compiler (amdgpu_waves_per_eu).  k_dec_sync_reg wants ~100
+// SGPRs, which caps it at 7 wavefronts per SIMD; asked for 8 the compiler parks ~24 of them in
+// VGPR lanes and the kernel is 11 % faster (0.52 -> 0.46 ms); 9 is out of reach.  k_dec_write_reg
+// is held at 6 workgroups per CU by its LDS, so the same request changes nothing there.
+#ifndef ET_SYNC_WAVES
+#define ET_SYNC_WAVES 8
+#endif
+#ifndef ET_WRITE_WAVES
+#define ET_WRITE_WAVES 0
+#endif
+#if ET_SYNC_WAVES
+#define ET_SYNC_ATTR __attribute__((amdgpu_waves_per_eu(ET_SYNC_WAVES, 10)))
+#else
+#define ET_SYNC_ATTR
+#endif
+#if ET_WRITE_WAVES
+#define ET_WRITE_ATTR __attribute__((amdgpu_waves_per_eu(ET_WRITE_WAVES, 10)))
+#else
+#define ET_WRITE_ATTR
+#endif
 template <bool FIRST, bool TICKET>
-__global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
-                                                        DecodeTables tb, uint32_t *__restrict__ sub_state,
+__global__ __launch_bounds__(BLOCK) ET_SYNC_ATTR void k_dec_sync_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+                                                        StepTableArgs ta, uint32_t *__restrict__ sub_state,
                                                         uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_count,
                                                         uint32_t *__restrict__ changed, uint32_t *__restrict__ ticket, uint32_t max_trips, uint32_t chunk,
                                                         const uint32_t *__restrict__ worklist, const uint32_t *__restrict__ n_work) {
     // LDS: step table, its second-level tables | exits | scratch
     uint32_t *steps = reinterpret_cast<uint32_t *>(dec_smem_raw);
-    const uint32_t step_words = step_table_words(tb);
+    const uint32_t step_words = ta.words;
+    const StepWalk sw = {steps, ta.slow, 32 - ta.step_bits, ta.step_bits, ta.sub_bits, 64 + ta.step_bits};
     DecodeSmem m;
     m.exits = steps + step_words;
     m.scratch = m.exits + BLOCK;
@@ -1422,7 +1474,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restri
                 load_window<true>(W, words, sub_g);
                 if (!staged) {
                     for (uint32_t i = tid * 4; i < step_words; i += BLOCK * 4)
-                        *reinterpret_cast<uint4 *>(steps + i) = *reinterpret_cast<const uint4 *>(tb.steps + i);
+                        *reinterpret_cast<uint4 *>(steps + i) = *reinterpret_cast<const uint4 *>(ta.table + i);
                     staged = true;
                     __syncthreads();
                 }
@@ -1436,9 +1488,9 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync_reg(const uint32_t *__restri
                         break;
                     }
                     if (need) {
-                        const SubResult r = warm      ? walk_steps<true>(steps, tb, W, 0, ck)
-                                            : have_ck ? rewalk_steps(steps, tb, W, cand, ck, exit_rel, count)
-                                                      : walk_steps<false>(steps, tb, W, cand, ck);
+                        const SubResult r = warm      ? walk_steps<true>(sw, W, 0, ck)
+                                            : have_ck ? rewalk_steps(sw, W, cand, ck, exit_rel, count)
+                                                      : walk_steps<false>(sw, W, cand, ck);
                         have_ck = true;
                         start = r.start_rel;
                         exit_rel = r.exit_rel;
@@ -1484,13 +1536,11 @@ __global__ __launch_bounds__(BLOCK) void k_dec_check(const uint32_t *__restrict_
 //   MODE 2: they are positions in the block's output; bytes in [lo, hi) go to stage[pos - lo].
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 template <int MODE>
-__device__ __forceinline__ void walk_write(const uint32_t *wsteps, const uint8_t *sym_len, uint8_t *smem8, const DecodeTables &tb,
-                                           const uint32_t (&W)[RW_WORDS], uint32_t start_rel, uint32_t pos0, uint32_t lo, uint32_t hi,
-                                           uint32_t stage_off) {
-    const uint32_t idx_shift = 32 - tb.step_bits;
-    const uint32_t *wsub = wsteps + (1u << tb.step_bits);
-    const uint32_t multi_floor = WSTEP_BIAS + tb.step_bits;
-    uint32_t X = (pos0 << 10) | (WSTEP_BIAS - 160 - start_rel), e = 0;
+__device__ __forceinline__ void walk_write(const StepWalk &sw, const uint8_t *sym_len, uint8_t *smem8, const uint32_t (&W)[RW_WORDS], uint32_t start_rel,
+                                           uint32_t pos0, uint32_t lo, uint32_t hi, uint32_t stage_off) {
+    const uint32_t *wsteps = sw.steps;
+    const uint32_t idx_shift = sw.idx_shift;
+    uint32_t X = (pos0 << 10) | (64 - start_rel), e = 0;  // low 10 bits: G as in walk_steps
 #define ET_F (X & 1023u)
 // MODE 1 positions are absolute LDS addresses minus one, used as integers (nothing to add,
 // and both of a step's stores get their -1 / +0 folded into the instruction's offset)
@@ -1512,9 +1562,9 @@ __device__ __forceinline__ void walk_write(const uint32_t *wsteps, const uint8_t
     {                                                                                                                  \
         const uint32_t w_ = __builtin_amdgcn_alignbit(hi_, lo_, X), t_ = e >> 24;                                      \
         uint32_t ent_ = 0;                                                                                             \
-        if (t_) ent_ = wsub[((t_ - 1) << tb.step_sub_bits) | ((w_ << tb.step_bits) >> (32 - tb.step_sub_bits))];      \
+        if (t_) ent_ = wsteps[(1u << sw.step_bits) + (((t_ - 1) << sw.sub_bits) | ((w_ << sw.step_bits) >> (32 - sw.sub_bits)))]; \
         if (ent_ == 0) {                                                                                               \
-            const uint32_t hit_ = decode_one_slow(tb.lut, tb.sym_len, tb.sub, tb.longc, tb.n_long, tb.lut_bits | (tb.sub_bits << 8), w_); \
+            const uint32_t hit_ = decode_one_slow_p(sw.slow, w_);                                                      \
             if (hit_) ent_ = ((hit_ & 0xffu) << 16) | ((1u << 10) - (hit_ >> 8));                                      \
         }                                                                                                              \
         if (ent_) {                                                                                                    \
@@ -1524,28 +1574,29 @@ __device__ __forceinline__ void walk_write(const uint32_t *wsteps, const uint8_t
             X -= 1; /* no code: one bit on, no symbol */                                                               \
         }                                                                                                              \
     }
-#define ET_WW_WORD(j_, hi_, lo_)                                                      \
+#define ET_WW_WORD(hi_, lo_)                                                          \
     for (;;) {                                                                        \
-        while (ET_F >= WSTEP_BIAS - 32 * ((j_) + 1)) ET_WW_STEP(hi_, lo_)             \
-        if (ET_F >= WSTEP_BIAS - 32 * ((j_) + 2)) break;                              \
+        while (ET_F >= 64) ET_WW_STEP(hi_, lo_)                                       \
+        if (ET_F >= 32) break;                                                        \
         X -= WSTEP_ESCAPE;                                                            \
         ET_WW_SLOW(hi_, lo_)                                                          \
-    }
-    ET_WW_WORD(4, W[3], W[4])  // only lanes that start at bit 0
-    ET_WW_WORD(5, W[4], W[5])
-    ET_WW_WORD(6, W[5], W[6])
-    ET_WW_WORD(7, W[6], W[7])
-    ET_WW_WORD(8, W[7], W[8])
-    ET_WW_WORD(9, W[8], W[9])
-    ET_WW_WORD(10, W[9], W[10])
-    ET_WW_WORD(11, W[10], W[11])
+    }                                                                                 \
+    X += 32;
+    ET_WW_WORD(W[3], W[4])  // only lanes that start at bit 0
+    ET_WW_WORD(W[4], W[5])
+    ET_WW_WORD(W[5], W[6])
+    ET_WW_WORD(W[6], W[7])
+    ET_WW_WORD(W[7], W[8])
+    ET_WW_WORD(W[8], W[9])
+    ET_WW_WORD(W[9], W[10])
+    ET_WW_WORD(W[10], W[11])
     for (;;) {  // the last word: two-symbol steps while step_bits bits are left, then one codeword at a time
-        while (ET_F >= multi_floor - 416) ET_WW_STEP(W[11], W[12])
-        if (ET_F >= WSTEP_BIAS - 416 - 32) break;
+        while (ET_F >= sw.multi_floor) ET_WW_STEP(W[11], W[12])
+        if (ET_F >= 32) break;
         X -= WSTEP_ESCAPE;
         ET_WW_SLOW(W[11], W[12])
     }
-    while (ET_F > WSTEP_BIAS - 416) {
+    while (ET_F > 64) {
         e = wsteps[__builtin_amdgcn_alignbit(W[11], W[12], X) >> idx_shift];
         if ((e & 0xffffu) != WSTEP_ESCAPE) {
             const uint32_t s1 = (e >> 16) & 0xffu;
@@ -1563,13 +1614,14 @@ __device__ __forceinline__ void walk_write(const uint32_t *wsteps, const uint8_t
 }
 
 // D3 for interior blocks (tickets of WRITE_CHUNK blocks, as k_dec_write).
-__global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
-                                                         DecodeTables tb, const uint32_t *__restrict__ sub_state,
+__global__ __launch_bounds__(BLOCK) ET_WRITE_ATTR void k_dec_write_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+                                                         StepTableArgs ta, const uint8_t *__restrict__ sym_len_g, const uint32_t *__restrict__ sub_state,
                                                          const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ ticket) {
     // LDS: step table, its second-level tables | code lengths | scratch | stage
     uint32_t *wsteps = reinterpret_cast<uint32_t *>(dec_smem_raw);
-    const uint32_t step_words = step_table_words(tb);
+    const uint32_t step_words = ta.words;
+    const StepWalk sw = {wsteps, ta.slow, 32 - ta.step_bits, ta.step_bits, ta.sub_bits, 64 + ta.step_bits};
     uint8_t *sym_len = reinterpret_cast<uint8_t *>(wsteps + step_words);
     uint32_t *scratch = wsteps + step_words + 64;
     const uint32_t stage_off = (step_words + 64 + 8) * sizeof(uint32_t);
@@ -1578,8 +1630,8 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restr
     const uint32_t lds_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)stage));  // the stage's LDS address
     const int tid = threadIdx.x;
     for (uint32_t i = tid * 4; i < step_words; i += BLOCK * 4)
-        *reinterpret_cast<uint4 *>(wsteps + i) = *reinterpret_cast<const uint4 *>(tb.steps + i);
-    sym_len[tid] = tb.sym_len[tid];
+        *reinterpret_cast<uint4 *>(wsteps + i) = *reinterpret_cast<const uint4 *>(ta.table + i);
+    sym_len[tid] = sym_len_g[tid];
     for (;;) {
         __syncthreads();  // tables staged (first trip); everybody is done with scratch[7] and the stage
         if (tid == 0) scratch[7] = atomicAdd(ticket, WRITE_CHUNK);
@@ -1609,9 +1661,9 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restr
                 const uint32_t win_hi = min(win + DEC_STAGE_BYTES, phase + n_out);
                 const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
                 if (one_window) {
-                    if (count) walk_write<1>(wsteps, sym_len, smem8, tb, W, start, lds_stage + my_lo - 1u, 0, 0, 0);
+                    if (count) walk_write<1>(sw, sym_len, smem8, W, start, lds_stage + my_lo - 1u, 0, 0, 0);
                 } else if (my_lo < win_hi && my_hi > win) {
-                    walk_write<2>(wsteps, sym_len, smem8, tb, W, start, my_lo, win, win_hi, stage_off);
+                    walk_write<2>(sw, sym_len, smem8, W, start, my_lo, win, win_hi, stage_off);
                 }
                 __syncthreads();
                 const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
@@ -1813,17 +1865,17 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
             const hipStream_t special = fork_special(side, stream);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
-            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             join_special(side, stream);
         } else if (iter == 0) {
-            hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+            hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         } else {
             if (worklist) {  // n_work zeroed by the caller
                 hipLaunchKernelGGL(k_dec_check, dim3((n_blocks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, sub_state, blk_exit, n_blocks, worklist, n_work);
-                hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks < 512 ? n_blocks : 512), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u, static_cast<const uint32_t *>(worklist), static_cast<const uint32_t *>(n_work));
+                hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks < 512 ? n_blocks : 512), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u, static_cast<const uint32_t *>(worklist), static_cast<const uint32_t *>(n_work));
             } else {
-                hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+                hipLaunchKernelGGL((k_dec_sync_reg<false, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, 1u, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             }
             // (not on the side lane: the fork/join events cost more than these ~5 us)
             hipLaunchKernelGGL(k_dec_sync<false>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
@@ -1873,7 +1925,7 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
         const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
         const hipStream_t special = fork_special(side, stream);
         hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u);
-        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket);
+        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket);
         join_special(side, stream);
         return;
     }
