@@ -1064,16 +1064,16 @@ __global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restric
 // into registers and the walk is unrolled PER WORD: iteration w reads the window with one
 // v_alignbit_b32 from the fixed register pair (word w-1, word w) while the bit offset
 // `sh` stays in [1, 32], then sh -= 32.  No rotation, no window addressing, no bitstream
-// in LDS (k_dec_write_reg: 7 instead of 5 workgroups per CU), ~1/3 fewer instructions
-// per step.  Only the last word of a stretch needs the multi/single phase split.
-// (one out-of-line copy for the 15 unrolled step sites; everything by value: a reference
-// argument would push the caller's table pointers into scratch memory)
+// in LDS.  Only the last word of a stretch needs the multi/single phase split.  The walk
+// state is one packed register and table entries are added to it (walk_steps, walk_write).
+// The slow path's search for a code longer than the first-level table (as long_code, with
+// every table in global memory).
 __device__ __forceinline__ uint32_t long_code_flat(const uint16_t *sub, const uint32_t *longc, uint32_t n_long, uint32_t bits, uint32_t e,
                                                   uint32_t window) {
     const uint32_t lut_bits = bits & 0xffu, sub_bits = bits >> 8;
     uint32_t hit = 0;
     if ((e >> LUT_SUB_SHIFT) & 1u) hit = sub[((e & 0xffu) << sub_bits) | ((window << lut_bits) >> (32 - sub_bits))];
-    if (hit == 0) {  // as long_code
+    if (hit == 0) {
         for (uint32_t i = 0; i < n_long; ++i) {
             const uint32_t meta = longc[2 * i + 1], l = meta >> 8;
             if (((window ^ longc[2 * i]) >> (32 - l)) == 0) {
@@ -1084,126 +1084,12 @@ __device__ __forceinline__ uint32_t long_code_flat(const uint16_t *sub, const ui
     }
     return hit;
 }
-__device__ __attribute__((noinline)) uint32_t long_code_cold(const uint16_t *sub, const uint32_t *longc, uint32_t n_long, uint32_t bits,
-                                                             uint32_t e, uint32_t window) {
-    return long_code_flat(sub, longc, n_long, bits, e, window);
-}
-
-// Tables only (no bitstream): lut | sub | sym_len | [exits] | scratch | [stage]
-template <bool WITH_EXITS>
-__device__ __forceinline__ DecodeSmem carve_decode_smem_reg(const DecodeTables &tb) {
-    DecodeSmem m;
-    m.sdata = nullptr;
-    m.lut = reinterpret_cast<uint32_t *>(dec_smem_raw);
-    m.sub = reinterpret_cast<uint16_t *>(m.lut + (1u << tb.lut_bits));
-    m.sym_len = reinterpret_cast<uint8_t *>(m.lut + (1u << tb.lut_bits) + sub_words(tb));
-    m.exits = m.lut + (1u << tb.lut_bits) + sub_words(tb) + 64;
-    m.scratch = m.exits + (WITH_EXITS ? BLOCK : 0);
-    m.stage = reinterpret_cast<uint8_t *>(m.scratch + 8);
-    return m;
-}
 
 #ifndef ET_RW_WARM_WORDS
 #define ET_RW_WARM_WORDS 4
 #endif
 constexpr int RW_WARM_WORDS = ET_RW_WARM_WORDS;  // run-in of k_dec_sync_reg, in words (A/B knob; the loads stay)
 constexpr int RW_WORDS = 13;  // W[j] = stream word 8 * sub - 4 + j (host order): 4 run-in words, 8 own, 1 beyond
-
-// WRITE / WARM as walk_subsequence.  stage_* as there.
-template <int WRITE, bool WARM>
-__device__ __forceinline__ SubResult walk_regs(const DecodeSmem &m, const DecodeTables &tb, const uint32_t (&W)[RW_WORDS],
-                                               uint32_t start_rel, uint32_t stage_pos, uint32_t stage_lo, uint32_t stage_hi) {
-    const uint32_t idx_shift = 32 - tb.lut_bits;
-    // The only walk state is nsh = -(bit offset of the position in word w-1), in [-32, -1]
-    // while iteration w has work: the window is {word w-1, word w} >> (32 + nsh), and
-    // v_alignbit_b32 takes the shift modulo 32, i.e. nsh itself.
-    int nsh;
-    uint32_t count = 0;
-    SubResult res;
-    res.start_rel = start_rel;
-
-#define ET_RW_STEP(hi_, lo_, COUNTING, SINGLE)                                                             \
-    {                                                                                                      \
-        const uint32_t window_ = __builtin_amdgcn_alignbit(hi_, lo_, static_cast<uint32_t>(nsh));          \
-        const uint32_t e_ = m.lut[window_ >> idx_shift];                                                   \
-        uint32_t n_ = (e_ >> LUT_N_SHIFT) & 3u, syms_ = (SINGLE) ? (e_ & 0xffu) : e_;                      \
-        uint32_t len_ = (SINGLE) ? m.sym_len[e_ & 0xffu] : ((e_ >> LUT_LEN_SHIFT) & 15u);                  \
-        if (n_ == 0) {                                                                                     \
-            const uint32_t hit_ = long_code_cold(m.sub, tb.longc, tb.n_long, tb.lut_bits | (tb.sub_bits << 8), e_, window_); \
-            len_ = hit_ ? (hit_ >> 8) : 1u; /* no code: resynchronise bit by bit */                       \
-            syms_ = hit_ & 0xffu;                                                                          \
-            n_ = hit_ ? 1u : 0u;                                                                           \
-        } else if (SINGLE) {                                                                               \
-            n_ = 1;                                                                                        \
-        }                                                                                                  \
-        if (COUNTING) {                                                                                    \
-            if (WRITE == 1) {                                                                              \
-                const uint32_t o_ = stage_pos + count;                                                     \
-                if (SINGLE) {                                                                              \
-                    if (n_) m.stage[o_] = static_cast<uint8_t>(syms_);                                     \
-                } else { /* second byte first, at o + (n == 2); then the first symbol at o */             \
-                    m.stage[o_ + (n_ >> 1)] = static_cast<uint8_t>(syms_ >> 8);                            \
-                    m.stage[o_] = static_cast<uint8_t>(syms_);                                             \
-                }                                                                                          \
-            } else if (WRITE == 2) {                                                                       \
-                for (uint32_t j_ = 0; j_ < n_; ++j_) {                                                     \
-                    const uint32_t o_ = stage_pos + count + j_;                                            \
-                    if (o_ >= stage_lo && o_ < stage_hi) m.stage[o_ - stage_lo] = static_cast<uint8_t>(syms_ >> (8 * j_)); \
-                }                                                                                          \
-            }                                                                                              \
-            count += n_;                                                                                   \
-        }                                                                                                  \
-        nsh -= static_cast<int>(len_);                                                                     \
-    }
-// a word all of whose lut_bits windows lie before the stretch's limit: multi-symbol steps only
-#define ET_RW_WORD(hi_, lo_, COUNTING)                              \
-    while (nsh >= -32) ET_RW_STEP(hi_, lo_, COUNTING, false)        \
-    nsh += 32;
-// the word whose END is the stretch's limit (both stretches end on a word boundary: bit 0
-// and bit SUB_BITS of the subsequence): multi-symbol steps while lut_bits bits are left
-// before the limit, then single symbols.  Leaves nsh alone: -32 - nsh is how far the
-// last codeword reached past the limit.
-#define ET_RW_LAST_WORD(hi_, lo_, COUNTING)                                       \
-    while (nsh >= multi_floor) ET_RW_STEP(hi_, lo_, COUNTING, false)              \
-    while (nsh > -32) ET_RW_STEP(hi_, lo_, COUNTING, true)
-    const int multi_floor = static_cast<int>(tb.lut_bits) - 32;  // position <= limit - lut_bits
-
-    if (WARM) {
-        nsh = -32;  // DEC_WARMUP_BITS before the subsequence = first bit of W[0]
-        ET_RW_WORD(0u, W[0], false)
-        ET_RW_WORD(W[0], W[1], false)
-        ET_RW_WORD(W[1], W[2], false)
-        ET_RW_WORD(W[2], W[3], false)
-        ET_RW_LAST_WORD(W[3], W[4], false)
-        res.start_rel = static_cast<uint32_t>(-32 - nsh);  // in [0, 31]; nsh is already what the next line wants
-    } else {
-        nsh = -32 - static_cast<int>(start_rel);
-    }
-    ET_RW_WORD(W[3], W[4], true)  // only lanes at bit 0 (nsh == -32) act here
-    ET_RW_WORD(W[4], W[5], true)
-    ET_RW_WORD(W[5], W[6], true)
-    ET_RW_WORD(W[6], W[7], true)
-    ET_RW_WORD(W[7], W[8], true)
-    ET_RW_WORD(W[8], W[9], true)
-    ET_RW_WORD(W[9], W[10], true)
-    ET_RW_WORD(W[10], W[11], true)
-    ET_RW_LAST_WORD(W[11], W[12], true)
-#undef ET_RW_LAST_WORD
-#undef ET_RW_WORD
-#undef ET_RW_STEP
-    res.exit_rel = static_cast<uint32_t>(-32 - nsh);
-    res.count = count;
-    return res;
-}
-
-// One codeword at the top of `window`, from the tables in GLOBAL memory (the slow path of
-// walk_steps: its step table said "no whole code inside the index").  (len << 8) | sym, 0 = no code.
-__device__ __attribute__((noinline)) uint32_t decode_one_slow(const uint32_t *lut, const uint8_t *sym_len, const uint16_t *sub,
-                                                              const uint32_t *longc, uint32_t n_long, uint32_t bits, uint32_t window) {
-    const uint32_t e = lut[window >> (32 - (bits & 0xffu))];
-    if ((e >> LUT_N_SHIFT) & 3u) return (static_cast<uint32_t>(sym_len[e & 0xffu]) << 8) | (e & 0xffu);
-    return long_code_flat(sub, longc, n_long, bits, e, window);  // (inlined: a leaf function needs no stack)
-}
 
 __host__ __device__ __forceinline__ uint32_t step_table_words(const DecodeTables &tb) {
     return ((1u << tb.step_bits) + (tb.n_step_sub << tb.step_sub_bits) + 3u) & ~3u;
@@ -1379,8 +1265,6 @@ __device__ __forceinline__ SubResult rewalk_steps(const StepWalk &sw, const uint
 #undef ET_SW_SLOW
 #undef ET_SW_STEP
 #undef ET_F
-
-__device__ __forceinline__ void stage_tables_reg(const DecodeSmem &m, const DecodeTables &tb) { stage_tables(m, tb); }
 
 // The words of lane `sub_g`'s subsequence (interior block: every index is inside the stream).
 template <bool WITH_RUN_IN>
