@@ -1095,6 +1095,11 @@ __host__ __device__ __forceinline__ uint32_t step_table_words(const DecodeTables
     return ((1u << tb.step_bits) + (tb.n_step_sub << tb.step_sub_bits) + 3u) & ~3u;
 }
 
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+#ifndef ET_ASM_WALK
+#define ET_ASM_WALK 1
+#endif
+
 // Kernel-argument form of a step table (DecodeTables::steps ...): the table in global
 // memory, its size in words (both levels, multiple of 4), and the device copy of the
 // DecodeTables for the slow path.
@@ -1139,11 +1144,47 @@ template <bool WARM>
 __device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32_t (&W)[RW_WORDS], uint32_t start_rel, uint32_t (&ck)[8]) {
     const uint32_t *steps = sw.steps;
     const uint32_t idx_shift = sw.idx_shift;
+    const uint32_t steps_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)steps));  // the table's LDS address
+    (void)steps_lds;
     uint32_t X, e = 0;
     SubResult res;
     res.start_rel = start_rel;
 #define ET_F static_cast<uint16_t>(X)
 #define ET_SW_STEP(hi_, lo_) X += (e = steps[__builtin_amdgcn_alignbit(hi_, lo_, X) >> idx_shift]);
+// The whole-index step loop of one word, hand-written: the compiler's version spends a
+// v_and + v_cmp on the 16-bit position field and three scalar instructions on the loop mask;
+// here v_cmp_le_u16 reads the low half directly and lanes that leave the word are dropped
+// from exec.  5 VALU + 1 LDS + 2 SALU per step.  floor_ = lowest G still in the word (an
+// inline constant or an SGPR).
+#if ET_ASM_WALK
+#define ET_SW_LOOP(hi_, lo_, floor_)                                                   \
+    {                                                                                  \
+        uint32_t t_;                                                                   \
+        uint64_t saved_;                                                               \
+        asm volatile(                                                                  \
+            "s_mov_b64 %[sv], exec\n\t"                                                \
+            "v_cmp_le_u16 vcc, %[fl], %[x]\n\t"                                        \
+            "s_and_b64 exec, exec, vcc\n\t"                                            \
+            "s_cbranch_execz 2f\n"                                                     \
+            "1:\n\t"                                                                   \
+            "v_alignbit_b32 %[t], %[hi], %[lo], %[x]\n\t"                              \
+            "v_lshrrev_b32 %[t], %[sh], %[t]\n\t"                                      \
+            "v_lshl_add_u32 %[t], %[t], 2, %[base]\n\t"                                \
+            "ds_read_b32 %[e], %[t]\n\t"                                               \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                 \
+            "v_add_u32 %[x], %[x], %[e]\n\t"                                           \
+            "v_cmp_le_u16 vcc, %[fl], %[x]\n\t"                                        \
+            "s_and_b64 exec, exec, vcc\n\t"                                            \
+            "s_cbranch_execnz 1b\n"                                                    \
+            "2:\n\t"                                                                   \
+            "s_mov_b64 exec, %[sv]"                                                    \
+            : [x] "+v"(X), [e] "+v"(e), [t] "=&v"(t_), [sv] "=&s"(saved_)              \
+            : [hi] "v"(hi_), [lo] "v"(lo_), [sh] "s"(idx_shift), [base] "v"(steps_lds), [fl] "s"(floor_) \
+            : "vcc");                                                                  \
+    }
+#else
+#define ET_SW_LOOP(hi_, lo_, floor_) while (ET_F >= (floor_)) ET_SW_STEP(hi_, lo_)
+#endif
 // the code at X is longer than the index (`e` is its escape entry): second-level table, else the slow way
 #define ET_SW_SLOW(hi_, lo_)                                                                                           \
     {                                                                                                                  \
@@ -1159,7 +1200,7 @@ __device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32
 // a word all of whose step_bits windows end before the stretch's limit
 #define ET_SW_WORD(hi_, lo_)                                                          \
     for (;;) {                                                                        \
-        while (ET_F >= 64) ET_SW_STEP(hi_, lo_)                                       \
+        ET_SW_LOOP(hi_, lo_, 64u)                                                     \
         if (ET_F >= 32) break;                                                        \
         X -= STEP_ESCAPE;                                                             \
         ET_SW_SLOW(hi_, lo_)                                                          \
@@ -1170,7 +1211,7 @@ __device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32
 // codeword reached past the limit.
 #define ET_SW_LAST_WORD(hi_, lo_)                                                     \
     for (;;) {                                                                        \
-        while (ET_F >= sw.multi_floor) ET_SW_STEP(hi_, lo_)                           \
+        ET_SW_LOOP(hi_, lo_, sw.multi_floor)                                          \
         if (ET_F >= 32) break;                                                        \
         X -= STEP_ESCAPE;                                                             \
         ET_SW_SLOW(hi_, lo_)                                                          \
@@ -1225,6 +1266,8 @@ __device__ __forceinline__ SubResult rewalk_steps(const StepWalk &sw, const uint
                                                   uint32_t old_exit, uint32_t old_count) {
     const uint32_t *steps = sw.steps;
     const uint32_t idx_shift = sw.idx_shift;
+    const uint32_t steps_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)steps));
+    (void)steps_lds;
     uint32_t X = 64 - start_rel, e = 0;
     SubResult res;
     res.start_rel = start_rel;
@@ -1418,7 +1461,6 @@ __global__ __launch_bounds__(BLOCK) void k_dec_check(const uint32_t *__restrict_
 // conditional and none leaves the lane's own slots.
 //   MODE 1: X's upper bits are LDS addresses - 1 (the whole block fits the stage).
 //   MODE 2: they are positions in the block's output; bytes in [lo, hi) go to stage[pos - lo].
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
 template <int MODE>
 __device__ __forceinline__ void walk_write(const StepWalk &sw, const uint8_t *sym_len, uint8_t *smem8, const uint32_t (&W)[RW_WORDS], uint32_t start_rel,
                                            uint32_t pos0, uint32_t lo, uint32_t hi, uint32_t stage_off) {
