@@ -132,6 +132,20 @@ bool read_file(const std::string &path, std::vector<uint8_t> &data) {  // main.z
     return n == 0 || static_cast<bool>(f.read(reinterpret_cast<char *>(data.data()), n));
 }
 
+// main.zig:199 leaves "validate the file" as a TODO; a file without the magic is refused here.
+std::string g_magic_why;
+bool magic_ok(int fd, et_ctx *) {
+    uint8_t first4[4] = {0, 0, 0, 0};
+    const char *why = nullptr;
+    if (::pread(fd, first4, 4, 0) != 4) {
+        g_magic_why = "file shorter than the 4-byte magic";
+        return false;
+    }
+    if (et_check_magic(first4, &why) == ET_OK) return true;
+    g_magic_why = why ? why : "bad magic";
+    return false;
+}
+
 void dump_dictionary(const et_codebook &cb) {  // encode.zig:204-212
     const unsigned leaves = cb.n_coded ? cb.n_coded : 1;
     for (unsigned i = 0; i < leaves; ++i) {
@@ -186,6 +200,8 @@ int main(int argc, char **argv) {
             if (opt.debug) std::printf("\nbits in output: %zu\n", written * 8);  // encode.zig:320
             reported = written;  // encode.zig:331,336: counts the bytes even with -t
         }
+    } else if (!magic_ok(in_fd, ctx)) {
+        rc = ET_ERR_FORMAT;
     } else if (!opt.print) {
         rc = et_decode_fd(ctx, in_fd, 4, out_fd, &in_size_bytes, &written);  // main.zig:204: text_in[4..]
         if (rc == ET_OK && !opt.dry) reported = written;  // decode.zig:185-188
@@ -214,7 +230,7 @@ int main(int argc, char **argv) {
         }
     }
     if (rc != ET_OK) {
-        std::fprintf(stderr, "error: %s: %s\n", et_strerror(rc), et_last_error(ctx));
+        std::fprintf(stderr, "error: %s: %s\n", et_strerror(rc), g_magic_why.empty() ? et_last_error(ctx) : g_magic_why.c_str());
         et_ctx_destroy(ctx);
         ::close(in_fd);
         if (out_fd >= 0) ::close(out_fd);

@@ -202,6 +202,15 @@ extern "C" int et_codebook_bits(const et_codebook *cb, const uint64_t hist[256],
     return ET_OK;
 }
 
+extern "C" int et_check_magic(const uint8_t first4[4], const char **why) {
+    const char *reason = nullptr;
+    if (!first4) return ET_ERR_ARG;
+    if (first4[0] != 0xe7 || first4[1] != 0xc0 || first4[2] != 0xde) reason = "not an .et file (magic e7 c0 de missing)";
+    else if (first4[3] != 0x01) reason = "unknown .et format version";
+    if (why) *why = reason;
+    return reason ? ET_ERR_FORMAT : ET_OK;
+}
+
 extern "C" int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols) {
     if (!compressed || !n_symbols) return ET_ERR_ARG;
     if (len < 5) return ET_ERR_FORMAT;

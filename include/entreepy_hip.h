@@ -128,6 +128,12 @@ int et_decode_fd(et_ctx *ctx, int in_fd, size_t in_skip, int out_fd, size_t *in_
  * encode.zig:204-212, which the reference prints from inside encode()). */
 int et_last_codebook(const et_ctx *ctx, et_codebook *out);
 
+/* The four bytes decode() never sees (main.zig:204 passes text_in[4..] unchecked, TODO at
+ * main.zig:199): magic e7 c0 de and format version 01 (encode.zig:262-266).  ET_OK, or
+ * ET_ERR_FORMAT with the reason in *why (static string; may be NULL).  The CLI refuses
+ * files that fail this check instead of decoding whatever follows. */
+int et_check_magic(const uint8_t first4[4], const char **why);
+
 /* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */
 int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols);
 

@@ -284,3 +284,19 @@ def test_file_pipeline_errors(tmp_path):
     junk.write_bytes(b"\xe7\xc0\xde\x01" + bytes(range(1, 200)))
     with pytest.raises(E.EntreepyError):
         c.decode_file(str(junk), str(tmp_path / "o2.txt"))
+
+
+def test_cli_refuses_files_without_the_magic(tmp_path, res_files):
+    """main.zig:199 leaves validation as a TODO and would decode whatever follows byte 4;
+    the CLI refuses such files (and leaves the created output empty, as a failed run of the
+    reference does, main.zig:192)."""
+    text = next(iter(res_files.values()))
+    bad = tmp_path / "not_et.et"
+    bad.write_bytes(text)
+    out = tmp_path / "o.txt"
+    r = subprocess.run([EXE, "d", str(bad), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 1 and "magic" in r.stderr and out.stat().st_size == 0
+    tiny = tmp_path / "tiny.et"
+    tiny.write_bytes(b"\xe7\xc0")
+    r = subprocess.run([EXE, "d", str(tiny), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 1

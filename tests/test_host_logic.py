@@ -162,3 +162,16 @@ def test_parse_header_reports_codes_longer_than_32_bits():
     with pytest.raises(E.EntreepyError) as ei:
         E.parse_header(header[4:])
     assert ei.value.status == N.ET_ERR_UNSUPPORTED
+
+
+def test_check_magic():
+    """The four bytes main.zig:204 strips unchecked (encode.zig:262-266 writes e7 c0 de 01)."""
+    import ctypes
+
+    from entreepy_amd import _native as N
+
+    why = ctypes.c_char_p()
+    assert N.lib().et_check_magic(bytes.fromhex("e7c0de01"), ctypes.byref(why)) == N.ET_OK and why.value is None
+    assert N.lib().et_check_magic(bytes.fromhex("e7c0de02"), ctypes.byref(why)) == N.ET_ERR_FORMAT and b"version" in why.value
+    assert N.lib().et_check_magic(b"PK\x03\x04", ctypes.byref(why)) == N.ET_ERR_FORMAT and b"magic" in why.value
+    assert N.lib().et_check_magic(bytes.fromhex("e7c0de01"), None) == N.ET_OK
