@@ -922,10 +922,13 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
 // X1: lane maps (stride map_stride bytes per subsequence) and the block's composed map.
 __global__ __launch_bounds__(BLOCK) void k_dec_maps(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit,
                                                     uint64_t n_subs, DecodeTables tb, uint32_t n_starts, uint32_t map_stride,
-                                                    uint8_t *__restrict__ lane_maps, uint8_t *__restrict__ blk_maps) {
+                                                    uint8_t *__restrict__ lane_maps, uint8_t *__restrict__ blk_maps, uint32_t special_only) {
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
-    const uint64_t b = blockIdx.x;
+    const uint32_t n_blocks_all = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
+    // special_only: grid 3, the stream's first/last blocks (k_dec_maps_reg has the rest)
+    const uint64_t b = special_only ? special_candidate(blockIdx.x, n_blocks_all) : blockIdx.x;
+    if (special_only && (b >= n_blocks_all || !special_block(b, n_bytes))) return;
     stage_tables(m, tb);
     Prefetch pf;
     prefetch_block(pf, words, b, n_bytes);
@@ -1014,10 +1017,12 @@ __global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restric
                                                        uint64_t n_subs, DecodeTables tb, uint32_t map_stride,
                                                        const uint8_t *__restrict__ lane_maps, const uint8_t *__restrict__ blk_in,
                                                        uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
-                                                       uint32_t *__restrict__ blk_count) {
+                                                       uint32_t *__restrict__ blk_count, uint32_t special_only) {
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
-    const uint64_t b = blockIdx.x;
+    const uint32_t n_blocks_all = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
+    const uint64_t b = special_only ? special_candidate(blockIdx.x, n_blocks_all) : blockIdx.x;  // as k_dec_maps
+    if (special_only && (b >= n_blocks_all || !special_block(b, n_bytes))) return;
     stage_tables(m, tb);
     Prefetch pf;
     prefetch_block(pf, words, b, n_bytes);
@@ -1454,6 +1459,76 @@ __global__ __launch_bounds__(BLOCK) void k_dec_check(const uint32_t *__restrict_
     if ((sub_state[static_cast<uint64_t>(b) * BLOCK] & 0xffu) != blk_exit[b - 1]) worklist[atomicAdd(n_work, 1u)] = b;
 }
 
+// X1 / X3 for interior blocks: the exhaustive path's walks over registers (walk_steps; the
+// step table of k_dec_sync_reg).  Same maps, same outputs as k_dec_maps / k_dec_resolve,
+// which keep the stream's first and last blocks.  LDS: step table | maps[BLOCK][32] | exits | scratch.
+__global__ __launch_bounds__(BLOCK) void k_dec_maps_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks, StepTableArgs ta,
+                                                        uint32_t n_starts, uint32_t map_stride, uint8_t *__restrict__ lane_maps,
+                                                        uint8_t *__restrict__ blk_maps) {
+    const uint64_t b = blockIdx.x;
+    if (b >= n_blocks || special_block(b, n_bytes)) return;
+    uint32_t *steps = reinterpret_cast<uint32_t *>(dec_smem_raw);
+    uint8_t *maps = reinterpret_cast<uint8_t *>(steps + ta.words);
+    const StepWalk sw = {steps, ta.slow, 32 - ta.step_bits, ta.step_bits, ta.sub_bits, 64 + ta.step_bits};
+    const int tid = threadIdx.x;
+    const uint64_t sub_g = b * BLOCK + tid;
+    for (uint32_t i = tid * 4; i < ta.words; i += BLOCK * 4) *reinterpret_cast<uint4 *>(steps + i) = *reinterpret_cast<const uint4 *>(ta.table + i);
+    uint32_t W[RW_WORDS], ck[8];
+    load_window<false>(W, words, sub_g);
+    __syncthreads();
+    for (uint32_t p = 0; p < 32; ++p) {
+        uint32_t e = 0;
+        if (p < n_starts) e = walk_steps<false>(sw, W, p, ck).exit_rel;
+        maps[tid * 32 + p] = static_cast<uint8_t>(e);
+        if (p + 1 >= n_starts && p + 1 >= map_stride) break;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < map_stride; k += 8)
+        *reinterpret_cast<uint2 *>(lane_maps + sub_g * map_stride + k) = *reinterpret_cast<const uint2 *>(maps + tid * 32 + k);
+    if (tid < 32) {
+        uint32_t sidx = tid;
+        if (static_cast<uint32_t>(tid) < n_starts)
+            for (uint32_t i = 0; i < BLOCK; ++i) sidx = maps[i * 32 + sidx];
+        blk_maps[b * 32 + tid] = static_cast<uint8_t>(sidx);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_dec_resolve_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks, StepTableArgs ta,
+                                                           uint32_t map_stride, const uint8_t *__restrict__ lane_maps,
+                                                           const uint8_t *__restrict__ blk_in, uint32_t *__restrict__ sub_state,
+                                                           uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_count) {
+    const uint64_t b = blockIdx.x;
+    if (b >= n_blocks || special_block(b, n_bytes)) return;
+    uint32_t *steps = reinterpret_cast<uint32_t *>(dec_smem_raw);
+    uint8_t *maps = reinterpret_cast<uint8_t *>(steps + ta.words);
+    uint32_t *exits = steps + ta.words + BLOCK * 32 / 4;
+    uint32_t *scratch = exits + BLOCK;
+    const StepWalk sw = {steps, ta.slow, 32 - ta.step_bits, ta.step_bits, ta.sub_bits, 64 + ta.step_bits};
+    const int tid = threadIdx.x;
+    const uint64_t sub_g = b * BLOCK + tid;
+    for (uint32_t i = tid * 4; i < ta.words; i += BLOCK * 4) *reinterpret_cast<uint4 *>(steps + i) = *reinterpret_cast<const uint4 *>(ta.table + i);
+    for (uint32_t k = 0; k < map_stride; k += 8)
+        *reinterpret_cast<uint2 *>(maps + tid * 32 + k) = *reinterpret_cast<const uint2 *>(lane_maps + sub_g * map_stride + k);
+    uint32_t W[RW_WORDS], ck[8];
+    load_window<false>(W, words, sub_g);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t sidx = blk_in[b];
+        for (uint32_t i = 0; i < BLOCK; ++i) {
+            exits[i] = sidx;
+            sidx = maps[i * 32 + sidx];
+        }
+    }
+    __syncthreads();
+    const uint32_t start = exits[tid];
+    const SubResult r = walk_steps<false>(sw, W, start, ck);
+    sub_state[sub_g] = start | (r.exit_rel << 8) | (r.count << 16);
+    uint32_t total;
+    block_exclusive_scan(r.count, scratch, &total);
+    if (tid == 0) blk_count[b] = total;
+    if (tid == BLOCK - 1) blk_exit[b] = r.exit_rel;
+}
+
 // The write walk over a lane's registers (et_kernels.h WSTEP_*): as walk_steps, with the
 // stage position riding in the state's upper bits.  A step stores two bytes: the second
 // symbol first, at (position after the step) - 1 -- for a one-symbol entry that is the
@@ -1824,12 +1899,16 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_groups = (n_blocks + 255) / 256;
     const size_t smem = decode_smem_bytes(tb, true);
-    hipLaunchKernelGGL(k_dec_maps, dim3(n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, n_starts, map_stride, lane_maps, blk_maps);
+    const bool reg = use_reg_kernels(n_blocks) && tb.steps != nullptr;
+    const size_t smem_reg = (step_table_words(tb) + BLOCK * 32 / 4 + BLOCK + 8) * sizeof(uint32_t);
+    if (reg) hipLaunchKernelGGL(k_dec_maps_reg, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), n_starts, map_stride, lane_maps, blk_maps);
+    hipLaunchKernelGGL(k_dec_maps, dim3(reg ? 3 : n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, n_starts, map_stride, lane_maps, blk_maps, reg ? 1u : 0u);
     hipLaunchKernelGGL(k_dec_compose, dim3(n_groups), dim3(BLOCK), 0, stream, blk_maps, n_blocks, grp_maps);
     // one workgroup walks all group maps (256 per LDS refill), then every group resolves its blocks
     hipLaunchKernelGGL(k_dec_chain, dim3(1), dim3(BLOCK), 0, stream, grp_maps, n_groups, static_cast<const uint8_t *>(nullptr), first_bit, grp_in);
     hipLaunchKernelGGL(k_dec_chain, dim3(n_groups), dim3(BLOCK), 0, stream, blk_maps, n_blocks, grp_in, 0u, blk_in);
-    hipLaunchKernelGGL(k_dec_resolve, dim3(n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, map_stride, lane_maps, blk_in, sub_state, blk_exit, blk_count);
+    if (reg) hipLaunchKernelGGL(k_dec_resolve_reg, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), map_stride, lane_maps, blk_in, sub_state, blk_exit, blk_count);
+    hipLaunchKernelGGL(k_dec_resolve, dim3(reg ? 3 : n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, map_stride, lane_maps, blk_in, sub_state, blk_exit, blk_count, reg ? 1u : 0u);
 }
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
