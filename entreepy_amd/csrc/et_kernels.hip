@@ -1782,9 +1782,17 @@ template <typename K>
 static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
     uint32_t g = MAX_GRID;
 #if ET_GRID_MODE
-    int dev = 0, cus = 256, per_cu = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) == hipSuccess && per_cu >= 1)
+    static thread_local int seen_dev = -1, cus = 256, per_cu = 0;  // (remembered: on the launch path)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != seen_dev) {
+        cus = 256;
+        per_cu = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess) per_cu = 0;
+        seen_dev = dev;
+    }
+    if (per_cu >= 1)
         g = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
     if (g > MAX_GRID) g = MAX_GRID;
 #endif
@@ -1829,9 +1837,19 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
 template <typename K>
 static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticketed) {
     if (!ticketed) return n_chunks;
-    int dev = 0, cus = 256, per_cu = 1;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    // (the queries are remembered per kernel and LDS size: they sit on the launch path)
+    static thread_local size_t seen_smem = ~static_cast<size_t>(0);
+    static thread_local int seen_dev = -1, cus = 256, per_cu = 1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != seen_dev || smem != seen_smem) {
+        cus = 256;
+        per_cu = 1;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        seen_dev = dev;
+        seen_smem = smem;
+    }
     const uint32_t g = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
     return n_chunks < g ? (n_chunks ? n_chunks : 1) : g;
 }
@@ -1839,9 +1857,14 @@ static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticke
 // `special` = the stream the three-workgroup launch goes to: the side lane's (made to wait
 // for everything enqueued on `stream` so far) or `stream` itself; join_special makes
 // `stream` wait for it again.
+// (fork_mark first, then the big launch on `stream`, then fork_special: the big kernel is
+// handed to the GPU two API calls earlier and the side lane still waits only for what was
+// enqueued before the mark.)
+static void fork_mark(const SideLane *side, hipStream_t stream) {
+    if (side) (void)hipEventRecord(side->fork, stream);
+}
 static hipStream_t fork_special(const SideLane *side, hipStream_t stream) {
     if (!side) return stream;
-    (void)hipEventRecord(side->fork, stream);
     (void)hipStreamWaitEvent(side->stream, side->fork, 0);
     return side->stream;
 }
@@ -1864,9 +1887,10 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
         const bool ticketed = chunk > 0;
         if (iter == 0 && ticketed) {
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+            fork_mark(side, stream);
+            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             const hipStream_t special = fork_special(side, stream);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
-            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             join_special(side, stream);
         } else if (iter == 0) {
             hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
@@ -1928,9 +1952,10 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (use_reg_kernels(n_blocks)) {
         const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
+        fork_mark(side, stream);
+        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket);
         const hipStream_t special = fork_special(side, stream);
         hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u);
-        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket);
         join_special(side, stream);
         return;
     }
