@@ -35,6 +35,7 @@ constexpr bool SYNC_TICKET = ET_SYNC_TICKET, WRITE_TICKET = ET_WRITE_TICKET;  //
 constexpr uint32_t DEC_FIRST_SWEEP_TRIPS = 6;                   // local fixed-point trips before a block is declared non-synchronising
 constexpr uint32_t DEC_REPAIR_SWEEP_TRIPS = 8;                  // same cap for the two speculatively enqueued repair sweeps
 constexpr uint32_t DEC_HAVE_START = 1, DEC_FRONT_OK = 2;       // k_dec_sync flags (ranges of a stream split over GPUs)
+constexpr uint32_t DEC_SPECIAL_SUPER = 8;                      // with DEC_SPECIAL_ONLY: the blocks of 16 KiB superblocks k_dec_sync_reg2 leaves out
 constexpr uint32_t DEC_SPECIAL_ONLY = 4;                       // k_dec_sync flag: first/last blocks only (k_dec_sync_reg has the rest)
 constexpr uint32_t DEC_FRONT_WORDS = 4;                        // words staged BEFORE the workgroup's 8 KiB (warm-up run-in)
 constexpr uint32_t DEC_WARMUP_BITS = DEC_FRONT_WORDS * 32;     // run-in before each subsequence in the first sync sweep

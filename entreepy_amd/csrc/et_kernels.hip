@@ -769,6 +769,18 @@ __device__ __forceinline__ uint64_t special_candidate(uint32_t i, uint32_t n_blo
     return c >= 4 ? c - 3 : ~0ull;  // i = 1 -> n-2, i = 2 -> n-1; never block 0 again
 }
 
+// k_dec_sync_reg2 works on superblocks of two blocks (512-bit lanes) and takes those whose
+// two blocks are both interior; the LDS-window kernel then gets the rest: blocks 0, 1 and
+// up to six at the end (workgroup i of a grid of 8).
+__device__ __forceinline__ bool super_interior(uint64_t s, uint64_t n_bytes, uint32_t n_blocks) {
+    return 2 * s + 1 < n_blocks && !special_block(2 * s, n_bytes) && !special_block(2 * s + 1, n_bytes);
+}
+__device__ __forceinline__ uint64_t special_candidate2(uint32_t i, uint32_t n_blocks) {
+    if (i < 2) return i;
+    const uint64_t c = static_cast<uint64_t>(n_blocks) + i;
+    return c >= 10 ? c - 8 : ~0ull;  // i = 2..7 -> n-6..n-1, never 0 or 1 again
+}
+
 // D1.  FIRST sweep: every subsequence runs in over the DEC_WARMUP_BITS before it (the
 // stream's very first one starts at first_bit, which is exact); lanes whose run-in
 // disagrees with their predecessor's exit are re-walked until the workgroup is
@@ -814,8 +826,13 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
         }
         if (flags & DEC_SPECIAL_ONLY) {
             if (!first_trip) break;
-            b0 = special_candidate(blockIdx.x, n_blocks);
-            if (b0 >= n_blocks || !special_block(b0, n_bytes)) break;
+            if (flags & DEC_SPECIAL_SUPER) {
+                b0 = special_candidate2(blockIdx.x, n_blocks);
+                if (b0 >= n_blocks || super_interior(b0 >> 1, n_bytes, n_blocks)) break;
+            } else {
+                b0 = special_candidate(blockIdx.x, n_blocks);
+                if (b0 >= n_blocks || !special_block(b0, n_bytes)) break;
+            }
         }
         if (b0 >= n_blocks) break;
         const uint64_t b1 = (flags & DEC_SPECIAL_ONLY) ? b0 + 1 : (b0 + SYNC_CHUNK < n_blocks ? b0 + SYNC_CHUNK : n_blocks);
@@ -1308,6 +1325,128 @@ __device__ __forceinline__ SubResult rewalk_steps(const StepWalk &sw, const uint
     }
     return res;
 }
+
+// ---- 512-bit lanes for the first sweep ------------------------------------------------
+// A lane that owns TWO consecutive subsequences pays the 128-bit run-in once per 512 bits
+// (22 word iterations per 512 bits instead of 26): W[] holds 4 run-in words, 16 own, 1
+// beyond.  The state arrays keep their 256-bit granularity (the lane produces both
+// entries), so the repair sweeps, the scan and D3 are unchanged.
+constexpr int RW2_WORDS = 21;
+struct Sub2Result {
+    uint32_t start_rel, exit1, count1, exit2, count2;
+};
+// one 256-bit half: the eight words from register pair (W[B+3], W[B+4]) on, then the last word
+#define ET_SW_HALF_PLAIN(B_)                \
+    ET_SW_WORD(W[(B_) + 3], W[(B_) + 4])    \
+    ET_SW_WORD(W[(B_) + 4], W[(B_) + 5])    \
+    ET_SW_WORD(W[(B_) + 5], W[(B_) + 6])    \
+    ET_SW_WORD(W[(B_) + 6], W[(B_) + 7])    \
+    ET_SW_WORD(W[(B_) + 7], W[(B_) + 8])    \
+    ET_SW_WORD(W[(B_) + 8], W[(B_) + 9])    \
+    ET_SW_WORD(W[(B_) + 9], W[(B_) + 10])   \
+    ET_SW_WORD(W[(B_) + 10], W[(B_) + 11])  \
+    ET_SW_LAST_WORD(W[(B_) + 11], W[(B_) + 12])
+#define ET_SW_HALF(B_, ck_)                 \
+    ET_SW_WORD(W[(B_) + 3], W[(B_) + 4])    \
+    ck_[0] = X;                             \
+    ET_SW_WORD(W[(B_) + 4], W[(B_) + 5])    \
+    ck_[1] = X;                             \
+    ET_SW_WORD(W[(B_) + 5], W[(B_) + 6])    \
+    ck_[2] = X;                             \
+    ET_SW_WORD(W[(B_) + 6], W[(B_) + 7])    \
+    ck_[3] = X;                             \
+    ET_SW_WORD(W[(B_) + 7], W[(B_) + 8])    \
+    ck_[4] = X;                             \
+    ET_SW_WORD(W[(B_) + 8], W[(B_) + 9])    \
+    ck_[5] = X;                             \
+    ET_SW_WORD(W[(B_) + 9], W[(B_) + 10])   \
+    ck_[6] = X;                             \
+    ET_SW_WORD(W[(B_) + 10], W[(B_) + 11])  \
+    ck_[7] = X;                             \
+    ET_SW_LAST_WORD(W[(B_) + 11], W[(B_) + 12])
+
+template <bool WARM>
+__device__ __forceinline__ Sub2Result walk_steps2(const StepWalk &sw, const uint32_t (&W)[RW2_WORDS], uint32_t start_rel, uint32_t (&ck1)[8]) {
+    const uint32_t *steps = sw.steps;
+    const uint32_t idx_shift = sw.idx_shift;
+    const uint32_t steps_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)steps));
+    (void)steps_lds;
+    uint32_t X, e = 0;
+    Sub2Result res;
+    res.start_rel = start_rel;
+    if (WARM) {
+        X = 64;
+        ET_SW_WORD(0u, W[0])
+        ET_SW_WORD(W[0], W[1])
+        ET_SW_WORD(W[1], W[2])
+        ET_SW_WORD(W[2], W[3])
+        ET_SW_LAST_WORD(W[3], W[4])
+        X &= 0xffffu;
+        res.start_rel = 64 - X;
+    } else {
+        X = 64 - start_rel;
+    }
+    ET_SW_HALF(0, ck1)
+    res.exit1 = 64 - (X & 0xffffu);
+    res.count1 = (X >> 16) & 0xfffu;
+    X &= 0xffffu;  // the second subsequence starts where the first one's last codeword ended, and counts from zero
+    ET_SW_HALF_PLAIN(8)  // (no checkpoints: a re-walk that reaches the second half is rare, it then walks all of it)
+    res.exit2 = 64 - (X & 0xffffu);
+    res.count2 = (X >> 16) & 0xfffu;
+    return res;
+}
+
+// rewalk_steps for a 512-bit lane: `r` holds the previous walk's results and is updated.
+// Once the new walk merges with the old one the rest -- also the whole second
+// subsequence -- stays as it is.
+__device__ __forceinline__ void rewalk_steps2(const StepWalk &sw, const uint32_t (&W)[RW2_WORDS], uint32_t start_rel, uint32_t (&ck1)[8],
+                                              Sub2Result &r) {
+    const uint32_t *steps = sw.steps;
+    const uint32_t idx_shift = sw.idx_shift;
+    const uint32_t steps_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)steps));
+    (void)steps_lds;
+    uint32_t X = 64 - start_rel, e = 0;
+    r.start_rel = start_rel;
+    bool merged = false;
+    uint32_t shift = 0;
+#define ET_RW2_CHECK(ck_, c_, hi_, lo_, count_)                                              \
+    if (!merged) {                                                                           \
+        ET_SW_WORD(hi_, lo_)                                                                 \
+        if (static_cast<uint16_t>(X) == static_cast<uint16_t>(ck_[c_])) {                    \
+            merged = true;                                                                   \
+            const uint32_t nc_ = (count_ + (X >> 16) - (ck_[c_] >> 16)) & 0xfffu;            \
+            shift = (nc_ - count_) << 16;                                                    \
+            count_ = nc_;                                                                    \
+        }                                                                                    \
+        ck_[c_] = X;                                                                         \
+    } else {                                                                                 \
+        ck_[c_] += shift;                                                                    \
+    }
+#define ET_RW2_HALF(B_, ck_, count_)                                 \
+    ET_RW2_CHECK(ck_, 0, W[(B_) + 3], W[(B_) + 4], count_)           \
+    ET_RW2_CHECK(ck_, 1, W[(B_) + 4], W[(B_) + 5], count_)           \
+    ET_RW2_CHECK(ck_, 2, W[(B_) + 5], W[(B_) + 6], count_)           \
+    ET_RW2_CHECK(ck_, 3, W[(B_) + 6], W[(B_) + 7], count_)           \
+    ET_RW2_CHECK(ck_, 4, W[(B_) + 7], W[(B_) + 8], count_)           \
+    ET_RW2_CHECK(ck_, 5, W[(B_) + 8], W[(B_) + 9], count_)           \
+    ET_RW2_CHECK(ck_, 6, W[(B_) + 9], W[(B_) + 10], count_)          \
+    ET_RW2_CHECK(ck_, 7, W[(B_) + 10], W[(B_) + 11], count_)
+    ET_RW2_HALF(0, ck1, r.count1)
+    if (merged) return;
+    ET_SW_LAST_WORD(W[11], W[12])
+    const uint32_t new_exit1 = 64 - (X & 0xffffu);
+    r.count1 = (X >> 16) & 0xfffu;
+    if (new_exit1 == r.exit1) return;  // the second subsequence starts where it started before
+    r.exit1 = new_exit1;
+    X &= 0xffffu;
+    ET_SW_HALF_PLAIN(8)
+    r.exit2 = 64 - (X & 0xffffu);
+    r.count2 = (X >> 16) & 0xfffu;
+#undef ET_RW2_HALF
+#undef ET_RW2_CHECK
+}
+#undef ET_SW_HALF
+#undef ET_SW_HALF_PLAIN
 #undef ET_SW_LAST_WORD
 #undef ET_SW_WORD
 #undef ET_SW_SLOW
@@ -1446,6 +1585,69 @@ __global__ __launch_bounds__(BLOCK) ET_SYNC_ATTR void k_dec_sync_reg(const uint3
             }
         }
         if (!TICKET && !worklist) break;
+    }
+}
+
+// D1, first sweep, 512-bit lanes: a workgroup takes a superblock of two blocks (16 KiB);
+// protocol and outputs as k_dec_sync_reg<true, true>.
+__global__ __launch_bounds__(BLOCK) ET_SYNC_ATTR void k_dec_sync_reg2(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+                                                                     StepTableArgs ta, uint32_t *__restrict__ sub_state,
+                                                                     uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_count,
+                                                                     uint32_t *__restrict__ changed, uint32_t *__restrict__ ticket,
+                                                                     uint32_t max_trips, uint32_t chunk) {
+    uint32_t *steps = reinterpret_cast<uint32_t *>(dec_smem_raw);
+    const StepWalk sw = {steps, ta.slow, 32 - ta.step_bits, ta.step_bits, ta.sub_bits, 64 + ta.step_bits};
+    uint32_t *exits = steps + ta.words;
+    uint32_t *scratch = exits + BLOCK;
+    const int tid = threadIdx.x;
+    const uint32_t n_super = n_blocks / 2;
+    for (uint32_t i = tid * 4; i < ta.words; i += BLOCK * 4) *reinterpret_cast<uint4 *>(steps + i) = *reinterpret_cast<const uint4 *>(ta.table + i);
+    for (uint64_t sb = 0, sb_end = 0;; ++sb) {
+        __syncthreads();  // table staged (first trip); everybody is done with scratch and exits
+        if (sb >= sb_end) {
+            if (tid == 0) scratch[7] = atomicAdd(ticket, chunk);
+            __syncthreads();
+            sb = scratch[7];
+            sb_end = sb + chunk;
+        }
+        if (sb >= n_super) break;
+        if (!super_interior(sb, n_bytes, n_blocks)) continue;
+        const uint64_t q = sb * BLOCK + tid;  // 512-bit lane index = subsequences 2q, 2q + 1
+        uint32_t W[RW2_WORDS], ck1[8];
+        {
+            const uint32_t *src = words + q * (2 * SUB_BITS / 32) - 4;
+#pragma unroll
+            for (int j = 0; j < RW2_WORDS; ++j) W[j] = __builtin_bswap32(src[j]);
+        }
+        Sub2Result r = walk_steps2<true>(sw, W, 0, ck1);
+        uint32_t start = r.start_rel;
+        for (uint32_t trip = 1;; ++trip) {
+            exits[tid] = r.exit2;
+            __syncthreads();
+            uint32_t cand = start;
+            if (tid > 0) cand = exits[tid - 1];
+            const bool need = cand != start;
+            if (!__syncthreads_or(need)) break;
+            if (trip == max_trips) {  // see k_dec_sync; BOTH blocks of the pair are marked for a redo
+                if (tid == 0) atomicAdd(changed + 1, 2u);
+                if (tid == 0 || tid == BLOCK / 2) start = 0xffu;
+                break;
+            }
+            if (need) {
+                rewalk_steps2(sw, W, cand, ck1, r);
+                start = cand;
+            }
+        }
+        sub_state[2 * q] = start | (r.exit1 << 8) | (r.count1 << 16);
+        sub_state[2 * q + 1] = r.exit1 | (r.exit2 << 8) | (r.count2 << 16);
+        uint32_t total;
+        const uint32_t before = block_exclusive_scan(r.count1 + r.count2, scratch, &total);
+        if (tid == BLOCK / 2) {  // symbols of lanes 0..127 = first block of the pair
+            blk_count[2 * sb] = before;
+            blk_count[2 * sb + 1] = total - before;
+        }
+        if (tid == BLOCK / 2 - 1) blk_exit[2 * sb] = r.exit2;
+        if (tid == BLOCK - 1) blk_exit[2 * sb + 1] = r.exit2;
     }
 }
 
@@ -1885,7 +2087,16 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
         const size_t smem_reg = (step_table_words(tb) + BLOCK + 8) * sizeof(uint32_t);
         static const uint32_t chunk = [] { const char *e = getenv("ET_SYNC_REG_TICKET"); return e ? static_cast<uint32_t>(atoi(e)) : 4u; }();  // blocks per ticket (0: one workgroup per block); measured 0/4/8/16
         const bool ticketed = chunk > 0;
-        if (iter == 0 && ticketed) {
+        static const bool lanes512 = [] { const char *e = getenv("ET_SYNC_LANE512"); return !(e && e[0] == '0'); }();  // A/B switch
+        if (iter == 0 && ticketed && lanes512 && n_blocks >= 16) {
+            if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+            const uint32_t chunk2 = chunk > 1 ? chunk / 2 : 1;  // superblocks per ticket
+            fork_mark(side, stream);
+            hipLaunchKernelGGL(k_dec_sync_reg2, dim3(decode_grid(k_dec_sync_reg2, smem_reg, (n_blocks / 2 + chunk2 - 1) / chunk2, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk2);
+            const hipStream_t special = fork_special(side, stream);
+            hipLaunchKernelGGL(k_dec_sync<true>, dim3(8), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY | DEC_SPECIAL_SUPER);
+            join_special(side, stream);
+        } else if (iter == 0 && ticketed) {
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
             fork_mark(side, stream);
             hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
