@@ -1331,6 +1331,12 @@ __device__ __forceinline__ SubResult rewalk_steps(const StepWalk &sw, const uint
 // (22 word iterations per 512 bits instead of 26): W[] holds 4 run-in words, 16 own, 1
 // beyond.  The state arrays keep their 256-bit granularity (the lane produces both
 // entries), so the repair sweeps, the scan and D3 are unchanged.
+// (checkpointed re-walks as in rewalk_steps cost this kernel a wavefront of occupancy for
+// the eight extra registers: 0.40 vs 0.39 ms -> off; a re-walked lane walks its first
+// subsequence again in full)
+#ifndef ET_REG2_CK
+#define ET_REG2_CK 0
+#endif
 constexpr int RW2_WORDS = 21;
 struct Sub2Result {
     uint32_t start_rel, exit1, count1, exit2, count2;
@@ -1386,7 +1392,11 @@ __device__ __forceinline__ Sub2Result walk_steps2(const StepWalk &sw, const uint
     } else {
         X = 64 - start_rel;
     }
+#if ET_REG2_CK
     ET_SW_HALF(0, ck1)
+#else
+    ET_SW_HALF_PLAIN(0)
+#endif
     res.exit1 = 64 - (X & 0xffffu);
     res.count1 = (X >> 16) & 0xfffu;
     X &= 0xffffu;  // the second subsequence starts where the first one's last codeword ended, and counts from zero
@@ -1409,6 +1419,9 @@ __device__ __forceinline__ void rewalk_steps2(const StepWalk &sw, const uint32_t
     r.start_rel = start_rel;
     bool merged = false;
     uint32_t shift = 0;
+#if !ET_REG2_CK
+#define ET_RW2_CHECK(ck_, c_, hi_, lo_, count_) ET_SW_WORD(hi_, lo_)
+#else
 #define ET_RW2_CHECK(ck_, c_, hi_, lo_, count_)                                              \
     if (!merged) {                                                                           \
         ET_SW_WORD(hi_, lo_)                                                                 \
@@ -1422,6 +1435,7 @@ __device__ __forceinline__ void rewalk_steps2(const StepWalk &sw, const uint32_t
     } else {                                                                                 \
         ck_[c_] += shift;                                                                    \
     }
+#endif
 #define ET_RW2_HALF(B_, ck_, count_)                                 \
     ET_RW2_CHECK(ck_, 0, W[(B_) + 3], W[(B_) + 4], count_)           \
     ET_RW2_CHECK(ck_, 1, W[(B_) + 4], W[(B_) + 5], count_)           \
@@ -2090,7 +2104,7 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
         static const bool lanes512 = [] { const char *e = getenv("ET_SYNC_LANE512"); return !(e && e[0] == '0'); }();  // A/B switch
         if (iter == 0 && ticketed && lanes512 && n_blocks >= 16) {
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-            const uint32_t chunk2 = chunk > 1 ? chunk / 2 : 1;  // superblocks per ticket
+            static const uint32_t chunk2 = [] { const char *e = getenv("ET_SYNC_REG2_TICKET"); return e && atoi(e) > 0 ? static_cast<uint32_t>(atoi(e)) : 4u; }();  // superblocks per ticket; measured 1 / 2 / 4 / 8 / 16: 0.54 / 0.37 / 0.35 / 0.37 / 0.44 ms
             fork_mark(side, stream);
             hipLaunchKernelGGL(k_dec_sync_reg2, dim3(decode_grid(k_dec_sync_reg2, smem_reg, (n_blocks / 2 + chunk2 - 1) / chunk2, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk2);
             const hipStream_t special = fork_special(side, stream);
