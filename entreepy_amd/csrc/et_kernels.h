@@ -25,7 +25,7 @@ constexpr uint32_t DEC_GUARD_WORDS = 4;                        // words a lane m
 #define ET_SYNC_TICKET 0
 #endif
 #ifndef ET_WRITE_CHUNK
-#define ET_WRITE_CHUNK 8
+#define ET_WRITE_CHUNK 4
 #endif
 #ifndef ET_WRITE_TICKET
 #define ET_WRITE_TICKET 1
