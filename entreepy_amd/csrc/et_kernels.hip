@@ -128,33 +128,38 @@ __device__ __forceinline__ Chunk load_chunk_in_tile(const uint8_t *__restrict__ 
 // cycles per wave-instruction, ~4.9 TB/s chip-wide), not occupancy.
 // Counters are u32 (a tile is at most 64 KiB); tile totals go out as u32,
 // workgroup totals as u64.
-#ifndef ET_HIST_ATOMIC_TOTAL
-#define ET_HIST_ATOMIC_TOTAL 0  // measured: K1 itself 27 us slower with the atomics in its tail, the reduce kernel costs 13 + launch
+// HIST_BLOCK threads share the workgroup's one set of counters: the 32 KiB of LDS allow only
+// 4 workgroups per CU (a fifth does not fit beside the others' 160 KiB exactly), so 256
+// threads meant 4 wavefronts per SIMD and a latency-bound kernel; 512 threads double the
+// loads in flight on the same LDS: 0.283 -> 0.227 ms at 1 GiB (1024 threads: 0.235).
+#ifndef ET_HIST_BLOCK
+#define ET_HIST_BLOCK 512
 #endif
-__global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
-                                                      uint32_t rounds_per_tile, uint32_t n_tiles,
-                                                      uint32_t *__restrict__ tile_hist,
-                                                      unsigned long long *__restrict__ block_hist, unsigned long long *__restrict__ hist) {
+constexpr int HIST_BLOCK = ET_HIST_BLOCK;
+__global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
+                                                           uint32_t rounds_per_tile, uint32_t n_tiles,
+                                                           uint32_t *__restrict__ tile_hist,
+                                                           unsigned long long *__restrict__ block_hist, unsigned long long *__restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint32_t sh[256 * 32];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 256 * 32; i += BLOCK) sh[i] = 0;
+    for (int i = tid; i < 256 * 32; i += HIST_BLOCK) sh[i] = 0;
     __syncthreads();
 
     uint32_t *mine = sh + (tid & 31);
-    unsigned long long acc = 0;  // thread `tid` owns bin `tid` of the workgroup total
+    unsigned long long acc = 0;  // thread `tid` < 256 owns bin `tid` of the workgroup total
     const uint64_t tile_bytes = static_cast<uint64_t>(rounds_per_tile) * ROUND_BYTES;
+    const uint32_t tile_chunks = rounds_per_tile * (ROUND_BYTES / 16);  // 16-byte chunks per tile
 
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(tid) * 16;
-        const bool interior = static_cast<uint64_t>(t) * tile_bytes >= lo && static_cast<uint64_t>(t + 1) * tile_bytes <= hi;
-        // Four 16-byte loads in flight per lane: the kernel is latency-bound on HBM,
-        // not on the (conflict-free) LDS atomics.
-        for (uint32_t r0 = 0; r0 < rounds_per_tile; r0 += 4) {
+        const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes;
+        const bool interior = t0 >= lo && t0 + tile_bytes <= hi;
+        // Four 16-byte loads in flight per lane, then their 64 (conflict-free) LDS atomics.
+        for (uint32_t c0 = tid; c0 < tile_chunks; c0 += 4 * HIST_BLOCK) {
             Chunk c[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 c[u].valid = 0;
-                if (r0 + u < rounds_per_tile) c[u] = load_chunk_in_tile(base, t0 + static_cast<uint64_t>(r0 + u) * ROUND_BYTES, lo, hi, interior);
+                if (c0 + u * HIST_BLOCK < tile_chunks) c[u] = load_chunk_in_tile(base, t0 + static_cast<uint64_t>(c0 + u * HIST_BLOCK) * 16, lo, hi, interior);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -177,26 +182,22 @@ __global__ __launch_bounds__(BLOCK) void k_hist_tiles(const uint8_t *__restrict_
         // Tile flush: thread = bin; sum (and clear) its 32 replicas, 16 bytes at a time.
         // Rotating the start by the bin keeps the 16-lane groups of ds_read_b128 on
         // different bank quads.
-        uint32_t total = 0;
-        uint4 *row = reinterpret_cast<uint4 *>(sh + tid * 32);
+        if (tid < 256) {
+            uint32_t total = 0;
+            uint4 *row = reinterpret_cast<uint4 *>(sh + tid * 32);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = (q + tid) & 7;
-            const uint4 v = row[j];
-            total += v.x + v.y + v.z + v.w;
-            row[j] = make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+                const int j = (q + tid) & 7;
+                const uint4 v = row[j];
+                total += v.x + v.y + v.z + v.w;
+                row[j] = make_uint4(0, 0, 0, 0);
+            }
+            tile_hist[static_cast<uint64_t>(t) * 256 + tid] = total;
+            acc += total;
         }
-        tile_hist[static_cast<uint64_t>(t) * 256 + tid] = total;
-        acc += total;
         __syncthreads();
     }
-#if ET_HIST_ATOMIC_TOTAL
-    // Workgroups finish at different times, so their 256 atomics each (2048 x 256 on 256
-    // addresses) hide under the kernel's tail; a separate reduce kernel cost 13 us + a launch.
-    if (acc) atomicAdd(hist + tid, acc);
-#else
-    block_hist[static_cast<uint64_t>(blockIdx.x) * 256 + tid] = acc;
-#endif
+    if (tid < 256) block_hist[static_cast<uint64_t>(blockIdx.x) * 256 + tid] = acc;
 }
 
 // Column sums of block_hist[n_rows][256] into hist[256] (zeroed beforehand).
@@ -1419,6 +1420,7 @@ __device__ __forceinline__ void rewalk_steps2(const StepWalk &sw, const uint32_t
     r.start_rel = start_rel;
     bool merged = false;
     uint32_t shift = 0;
+    (void)shift;
 #if !ET_REG2_CK
 #define ET_RW2_CHECK(ck_, c_, hi_, lo_, count_) ET_SW_WORD(hi_, lo_)
 #else
@@ -2017,13 +2019,14 @@ static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist) {
-    const uint32_t grid = n_tiles < MAX_GRID ? n_tiles : MAX_GRID;  // over-subscribed on purpose: an exact-residency grid measured slower for K1
+    // 4 workgroups per CU are resident (LDS): 1024 = one full batch (0.227 ms at 1 GiB; 2048 = two
+    // batches 0.231; 1280 or 1536 = a full and a partial batch, 0.32-0.36)
+    static const uint32_t want = [] { const char *e = getenv("ET_HIST_GRID"); return e && atoi(e) > 0 && atoi(e) <= static_cast<int>(MAX_GRID) ? static_cast<uint32_t>(atoi(e)) : 1024u; }();
+    const uint32_t grid = n_tiles < want ? n_tiles : want;
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
-    hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
-#if !ET_HIST_ATOMIC_TOTAL
+    hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(HIST_BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
     const uint32_t rgrid = grid < 512 ? grid : 512;
     hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
-#endif
 }
 
 
