@@ -33,6 +33,25 @@ __global__ __launch_bounds__(256) void k_read_tiles(const uint4 *__restrict__ p,
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
+// K4's traffic without its arithmetic: a workgroup reads 64 KiB tiles round by round (4 KiB,
+// next round prefetched) and after every round stores 600 dwords (0.586 of what it read).
+__global__ __launch_bounds__(256) void k_rw_tiles(const uint4 *__restrict__ p, uint32_t n_tiles, uint32_t *__restrict__ q, uint32_t *out) {
+    uint32_t acc = 0;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint4 *base = p + static_cast<size_t>(t) * 4096 + threadIdx.x;
+        uint32_t *dst = q + static_cast<size_t>(t) * 9600;
+        uint4 cur = base[0];
+        for (int r = 0; r < 16; ++r) {
+            uint4 nxt = cur;
+            if (r + 1 < 16) nxt = base[(r + 1) * 256];
+            acc += cur.x ^ cur.y ^ cur.z ^ cur.w;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < 600; i += 256) dst[r * 600 + i] = acc + i;
+            cur = nxt;
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
 template <typename F>
 static float timeit(F f) {
     hipEvent_t a, b;
@@ -50,6 +69,12 @@ int main() {
     uint4 *d; uint32_t *o;
     hipMalloc(&d, n); hipMalloc(&o, 64);
     hipMemset(d, 1, n);
+    uint32_t *q;
+    hipMalloc(&q, n);
+    for (int grid : {1024, 2048, 4096}) {
+        float a = timeit([&] { hipLaunchKernelGGL(k_rw_tiles, dim3(grid), dim3(256), 0, 0, d, static_cast<uint32_t>(n / 65536), q, o); });
+        printf("grid %5d: K4 traffic pattern (read 1 GiB, write 0.586 GiB) %.3f ms (%.2f TB/s of traffic)\n", grid, a, n * 1.586 / a / 1e9);
+    }
     for (int grid : {1024, 1280, 2048, 4096, 8192, 16384}) {
         float a = timeit([&] { hipLaunchKernelGGL(k_read<4>, dim3(grid), dim3(256), 0, 0, d, n / 16, o); });
         float b = timeit([&] { hipLaunchKernelGGL(k_read<8>, dim3(grid), dim3(256), 0, 0, d, n / 16, o); });
