@@ -89,6 +89,8 @@ SIGNATURES = {
     "et_encode_head_shard_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _vp, _sz, _vp, _sz, _u64p]),
     "et_parse_header": (ctypes.c_int, [_vp, _sz, _cbp, _u64p, _szp]),
     "et_decode_range_sync": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _sz, ctypes.c_int, ctypes.c_int32, ctypes.POINTER(RangeInfo)]),
+    "et_decode_range_maps": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _sz, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8 * 32), ctypes.POINTER(ctypes.c_uint32)]),
+    "et_decode_range_resolve": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.POINTER(RangeInfo)]),
     "et_decode_range_write": (ctypes.c_int, [_vp, _u64, _vp, _sz, _szp]),
     "et_decode_body_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, ctypes.c_uint32, _u64, _vp, _sz, _szp]),
 }

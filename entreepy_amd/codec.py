@@ -284,6 +284,23 @@ class Context:
                                             int(begin >= 16), int(in_start_bit), ctypes.byref(info)), self._h)
         return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps}
 
+    def decode_range_maps(self, codebook, stream, begin, end, in_start_bit=-1):
+        """Exhaustive variant of decode_range_sync for codes that do not self-synchronise:
+        -> (map, n_starts), map[p] = exit bit of the range when its first codeword begins
+        p bits in (p < n_starts; constant when in_start_bit >= 0).  Follow with
+        decode_range_resolve(start) once the start is known."""
+        m = (ctypes.c_uint8 * 32)()
+        k = ctypes.c_uint32(0)
+        tail = stream.numel() - end
+        _check(N.lib().et_decode_range_maps(self._h, ctypes.byref(codebook.raw), stream.data_ptr() + begin, end - begin, tail, int(in_start_bit),
+                                            ctypes.byref(m), ctypes.byref(k)), self._h)
+        return bytes(m), k.value
+
+    def decode_range_resolve(self, in_start_bit):
+        info = N.RangeInfo()
+        _check(N.lib().et_decode_range_resolve(self._h, int(in_start_bit), ctypes.byref(info)), self._h)
+        return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps}
+
     def decode_range_write(self, max_symbols, out):
         n = ctypes.c_size_t(0)
         _check(N.lib().et_decode_range_write(self._h, int(max_symbols), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)

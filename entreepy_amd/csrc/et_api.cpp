@@ -92,6 +92,9 @@ struct et_ctx {
         uint64_t n_bytes = 0, n_subs = 0, total = 0;
         uint32_t n_blocks = 0, flags = 0;
         et::DecodeTables tb = {}, tb_write = {};
+        // et_decode_range_maps -> et_decode_range_resolve
+        bool maps_valid = false, maps_const = false;
+        uint32_t map_stride = 0;
     } range;
 };
 
@@ -1066,6 +1069,94 @@ extern "C" int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const vo
     info->n_symbols = rs.total;
     info->sweeps = sweeps;
     info->reserved = 0;
+    return ET_OK;
+}
+
+extern "C" int et_decode_range_maps(et_ctx *ctx, const et_codebook *cb, const void *d_range, size_t range_bytes, size_t tail_bytes,
+                                    int32_t in_start_bit, uint8_t map[32], uint32_t *n_starts_out) {
+    if (!ctx || !cb || !d_range || !map || !n_starts_out || range_bytes == 0) return ET_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_range) & 3) return fail(ctx, ET_ERR_ARG, "d_range must be 4-byte aligned");
+    if (tail_bytes && (range_bytes % (et::DEC_BLOCK_WORDS * 4) || tail_bytes < 16)) return fail(ctx, ET_ERR_ARG, "an inner range is a multiple of 8192 bytes with >= 16 bytes after it");
+    if (in_start_bit >= 32) return fail(ctx, ET_ERR_ARG, "in_start_bit must be < 32");
+    if (cb->max_length > 32) return fail(ctx, ET_ERR_UNSUPPORTED, "code length > 32");
+    if (cb->n_coded == 0) return fail(ctx, ET_ERR_ARG, "empty code table");
+    DeviceGuard guard(ctx->device);
+    const uint32_t *words = static_cast<const uint32_t *>(d_range);
+    const uint64_t n_bytes = static_cast<uint64_t>(range_bytes) + tail_bytes;
+    const uint64_t n_subs = (static_cast<uint64_t>(range_bytes) * 8 + et::SUB_BITS - 1) / et::SUB_BITS;
+    const uint64_t n_blocks64 = (n_subs + et::BLOCK - 1) / et::BLOCK;
+    if (n_blocks64 > 0x7fffffffull) return fail(ctx, ET_ERR_ARG, "range too large");
+    const uint32_t n_blocks = static_cast<uint32_t>(n_blocks64);
+    auto &rs = ctx->range;
+    rs.valid = rs.maps_valid = false;
+    const uint32_t n_starts = cb->max_length;
+    const uint32_t stride = n_starts <= 8 ? 8 : (n_starts <= 16 ? 16 : 32);
+    const size_t n_groups = (static_cast<size_t>(n_blocks) + 255) / 256;
+    ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+    ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
+    ET_TRY(ensure(ctx, ctx->lane_maps, n_subs * stride + 64));
+    ET_TRY(ensure(ctx, ctx->blk_maps, static_cast<size_t>(n_blocks) * 32 + 64));
+    ET_TRY(ensure(ctx, ctx->grp_maps, n_groups * 32 + 64));
+    ET_TRY(ensure(ctx, ctx->blk_in, static_cast<size_t>(n_blocks) + 64));
+    ET_TRY(ensure(ctx, ctx->grp_in, n_groups + 64));
+    ET_TRY(prepare_decode_tables(ctx, cb, &rs.tb, &rs.tb_write));
+    rs.words = words;
+    rs.n_bytes = n_bytes;
+    rs.n_subs = n_subs;
+    rs.n_blocks = n_blocks;
+    rs.flags = 0;
+    rs.map_stride = stride;
+    rs.maps_const = in_start_bit >= 0;
+    et::launch_dec_maps(ctx->stream, words, n_bytes, in_start_bit >= 0 ? static_cast<uint32_t>(in_start_bit) : 0u, rs.maps_const, n_subs, rs.tb, n_starts, stride,
+                        static_cast<uint8_t *>(ctx->lane_maps.p), static_cast<uint8_t *>(ctx->blk_maps.p), static_cast<uint8_t *>(ctx->grp_maps.p));
+    ET_HIP(hipGetLastError());
+    // last level on the host: compose the group maps (32 bytes per 2 MiB of stream)
+    std::vector<uint8_t> grp(n_groups * 32);
+    ET_HIP(hipMemcpyAsync(grp.data(), ctx->grp_maps.p, grp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint32_t p = 0; p < 32; ++p) {
+        uint32_t sidx = p;
+        if (p < n_starts || rs.maps_const)
+            for (size_t g = 0; g < n_groups; ++g) sidx = grp[g * 32 + sidx];
+        map[p] = static_cast<uint8_t>(sidx);
+    }
+    *n_starts_out = n_starts;
+    rs.maps_valid = true;
+    return ET_OK;
+}
+
+extern "C" int et_decode_range_resolve(et_ctx *ctx, uint32_t in_start_bit, et_range_info *info) {
+    if (!ctx || !info) return ET_ERR_ARG;
+    auto &rs = ctx->range;
+    if (!rs.maps_valid) return fail(ctx, ET_ERR_ARG, "et_decode_range_resolve needs et_decode_range_maps first");
+    if (in_start_bit >= 32) return fail(ctx, ET_ERR_ARG, "in_start_bit must be < 32");
+    DeviceGuard guard(ctx->device);
+    uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
+    uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
+    uint32_t *blk_count = static_cast<uint32_t *>(ctx->blk_count.p);
+    unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
+    uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 2);
+    et::launch_dec_resolve(ctx->stream, rs.words, rs.n_bytes, in_start_bit, rs.maps_const, rs.n_subs, rs.tb, rs.map_stride,
+                           static_cast<const uint8_t *>(ctx->lane_maps.p), static_cast<const uint8_t *>(ctx->blk_maps.p),
+                           static_cast<const uint8_t *>(ctx->grp_maps.p), static_cast<uint8_t *>(ctx->blk_in.p), static_cast<uint8_t *>(ctx->grp_in.p),
+                           sub_state, blk_exit, blk_count);
+    et::launch_dec_scan(ctx->stream, blk_count, rs.n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), blk_off);
+    ET_HIP(hipGetLastError());
+    ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + rs.n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipMemcpyAsync(h_flags, sub_state, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipMemcpyAsync(h_flags + 1, blk_exit + (rs.n_blocks - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    rs.total = ctx->h_scalar[1];
+    rs.flags = et::DEC_HAVE_START;
+    rs.valid = true;
+    info->start_bit = h_flags[0] & 0xffu;
+    info->exit_bit = h_flags[1];
+    info->n_symbols = rs.total;
+    info->sweeps = 0;
+    info->reserved = 1;  // exhaustive
     return ET_OK;
 }
 

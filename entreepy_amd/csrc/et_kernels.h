@@ -111,6 +111,11 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket,
                      uint32_t flags = DEC_HAVE_START, uint32_t *worklist = nullptr, uint32_t *n_work = nullptr, const SideLane *side = nullptr,
                      bool ticket_is_zero = false);
+void launch_dec_maps(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, bool have_start, uint64_t n_subs,
+                     const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps, uint8_t *grp_maps);
+void launch_dec_resolve(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, bool const_first, uint64_t n_subs,
+                        const DecodeTables &tb, uint32_t map_stride, const uint8_t *lane_maps, const uint8_t *blk_maps, const uint8_t *grp_maps,
+                        uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count);
 void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                            const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
                            uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,

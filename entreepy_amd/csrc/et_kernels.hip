@@ -940,7 +940,11 @@ __global__ __launch_bounds__(BLOCK) void k_dec_sync(const uint32_t *__restrict__
 // X1: lane maps (stride map_stride bytes per subsequence) and the block's composed map.
 __global__ __launch_bounds__(BLOCK) void k_dec_maps(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit,
                                                     uint64_t n_subs, DecodeTables tb, uint32_t n_starts, uint32_t map_stride,
-                                                    uint8_t *__restrict__ lane_maps, uint8_t *__restrict__ blk_maps, uint32_t special_only) {
+                                                    uint8_t *__restrict__ lane_maps, uint8_t *__restrict__ blk_maps, uint32_t special_only,
+                                                    uint32_t have_start) {
+    // have_start: the first subsequence starts exactly at first_bit (a stream's beginning, or a
+    // range whose start is known): its map is constant.  Otherwise (a range of a stream split
+    // over GPUs, et_decode_range_maps) it is a subsequence like any other.
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
     const uint32_t n_blocks_all = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
@@ -959,14 +963,14 @@ __global__ __launch_bounds__(BLOCK) void k_dec_maps(const uint32_t *__restrict__
     uint8_t *maps = m.stage;  // [BLOCK][32]
     for (uint32_t p = 0; p < 32; ++p) {
         uint32_t e = 0;
-        if (live && (p < n_starts || sub_g == 0)) {
-            const uint32_t st = sub_g == 0 ? first_bit : p;  // the stream's first subsequence has one start, whatever comes in
+        if (live && (p < n_starts || (sub_g == 0 && have_start))) {
+            const uint32_t st = (sub_g == 0 && have_start) ? first_bit : p;  // the stream's first subsequence has one start, whatever comes in
             const SubResult r = lim != 0xffffffffu ? walk_subsequence<0, true, false>(m, tb, tid, st, lim, 0, 0, 0)
                                                    : walk_subsequence<0, false, false>(m, tb, tid, st, lim, 0, 0, 0);
             e = r.exit_rel;
         }
         maps[tid * 32 + p] = static_cast<uint8_t>(e);
-        if (p + 1 >= n_starts && !(b == 0)) break;  // block 0 fills all 32 entries for its first lane
+        if (p + 1 >= n_starts && !(b == 0 && have_start)) break;  // block 0 fills all 32 entries for its first lane
     }
     __syncthreads();
     if (live) {
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_maps(const uint32_t *__restrict__
     const uint32_t n_live = static_cast<uint32_t>(n_subs - b * BLOCK >= BLOCK ? BLOCK : n_subs - b * BLOCK);
     if (tid < 32) {
         uint32_t sidx = tid;
-        if (static_cast<uint32_t>(tid) < n_starts || b == 0)
+        if (static_cast<uint32_t>(tid) < n_starts || (b == 0 && have_start))
             for (uint32_t i = 0; i < n_live; ++i) sidx = maps[i * 32 + sidx];
         blk_maps[b * 32 + tid] = static_cast<uint8_t>(sidx);
     }
@@ -1035,7 +1039,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restric
                                                        uint64_t n_subs, DecodeTables tb, uint32_t map_stride,
                                                        const uint8_t *__restrict__ lane_maps, const uint8_t *__restrict__ blk_in,
                                                        uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
-                                                       uint32_t *__restrict__ blk_count, uint32_t special_only) {
+                                                       uint32_t *__restrict__ blk_count, uint32_t special_only, uint32_t const_first) {
     const DecodeSmem m = carve_decode_smem(tb);
     const int tid = threadIdx.x;
     const uint32_t n_blocks_all = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_resolve(const uint32_t *__restric
             m.exits[i] = sidx;
             // the stream's first subsequence has a constant map, of which only the first
             // map_stride entries were stored; first_bit may lie beyond them
-            sidx = maps[i * 32 + ((b == 0 && i == 0) ? 0u : sidx)];
+            sidx = maps[i * 32 + ((b == 0 && i == 0 && const_first) ? 0u : sidx)];
         }
     }
     __syncthreads();
@@ -2143,24 +2147,44 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
 }
 
 // Exhaustive synchronisation (see k_dec_maps).  Workspaces: lane_maps n_subs * stride,
-// blk_maps / blk_in per block, grp_maps / grp_in per 256 blocks, top_maps per 65536.
-void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
-                           const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
-                           uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,
-                           uint32_t *blk_count) {
+// blk_maps / blk_in per block, grp_maps / grp_in per 256 blocks.  Two halves: the maps up to
+// one per 256 blocks (launch_dec_maps), and, once the input start is known, the way back down
+// and the counting walk (launch_dec_resolve).  A single GPU runs them back to back; ranges of
+// a stream split over GPUs exchange their composed maps in between.
+void launch_dec_maps(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, bool have_start, uint64_t n_subs,
+                     const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps, uint8_t *grp_maps) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_groups = (n_blocks + 255) / 256;
     const size_t smem = decode_smem_bytes(tb, true);
     const bool reg = use_reg_kernels(n_blocks) && tb.steps != nullptr;
     const size_t smem_reg = (step_table_words(tb) + BLOCK * 32 / 4 + BLOCK + 8) * sizeof(uint32_t);
     if (reg) hipLaunchKernelGGL(k_dec_maps_reg, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), n_starts, map_stride, lane_maps, blk_maps);
-    hipLaunchKernelGGL(k_dec_maps, dim3(reg ? 3 : n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, n_starts, map_stride, lane_maps, blk_maps, reg ? 1u : 0u);
+    hipLaunchKernelGGL(k_dec_maps, dim3(reg ? 3 : n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, n_starts, map_stride, lane_maps, blk_maps, reg ? 1u : 0u, have_start ? 1u : 0u);
     hipLaunchKernelGGL(k_dec_compose, dim3(n_groups), dim3(BLOCK), 0, stream, blk_maps, n_blocks, grp_maps);
+}
+
+void launch_dec_resolve(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, bool const_first, uint64_t n_subs,
+                        const DecodeTables &tb, uint32_t map_stride, const uint8_t *lane_maps, const uint8_t *blk_maps, const uint8_t *grp_maps,
+                        uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count) {
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
+    const uint32_t n_groups = (n_blocks + 255) / 256;
+    const size_t smem = decode_smem_bytes(tb, true);
+    const bool reg = use_reg_kernels(n_blocks) && tb.steps != nullptr;
+    const size_t smem_reg = (step_table_words(tb) + BLOCK * 32 / 4 + BLOCK + 8) * sizeof(uint32_t);
     // one workgroup walks all group maps (256 per LDS refill), then every group resolves its blocks
     hipLaunchKernelGGL(k_dec_chain, dim3(1), dim3(BLOCK), 0, stream, grp_maps, n_groups, static_cast<const uint8_t *>(nullptr), first_bit, grp_in);
     hipLaunchKernelGGL(k_dec_chain, dim3(n_groups), dim3(BLOCK), 0, stream, blk_maps, n_blocks, grp_in, 0u, blk_in);
     if (reg) hipLaunchKernelGGL(k_dec_resolve_reg, dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), map_stride, lane_maps, blk_in, sub_state, blk_exit, blk_count);
-    hipLaunchKernelGGL(k_dec_resolve, dim3(reg ? 3 : n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, map_stride, lane_maps, blk_in, sub_state, blk_exit, blk_count, reg ? 1u : 0u);
+    hipLaunchKernelGGL(k_dec_resolve, dim3(reg ? 3 : n_blocks), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, tb, map_stride, lane_maps, blk_in, sub_state, blk_exit, blk_count, reg ? 1u : 0u, const_first ? 1u : 0u);
+}
+
+void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
+                           const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
+                           uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,
+                           uint32_t *blk_count) {
+    launch_dec_maps(stream, words, n_bytes, first_bit, true, n_subs, tb, n_starts, map_stride, lane_maps, blk_maps, grp_maps);
+    launch_dec_resolve(stream, words, n_bytes, first_bit, true, n_subs, tb, map_stride, lane_maps, blk_maps, grp_maps, blk_in, grp_in, sub_state, blk_exit,
+                       blk_count);
 }
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,

@@ -164,7 +164,25 @@ class ShardedCodec:
         begin, end = lo_b * 8192, min(hi_b * 8192, stream.numel())
         active = hi_b > lo_b and cb.raw.n_coded > 0 and n_symbols > 0
         info = {"start_bit": 0, "exit_bit": 0, "n_symbols": 0}
-        if active:
+        # Near-fixed-length codes do not self-synchronise: run-ins find nothing.  Every rank then
+        # computes its range's exit for each possible start (et_decode_range_maps), the 32-byte
+        # maps are all-gathered and chained from the stream's start, and each rank resolves its
+        # range with the start that reaches it -- one exchange, no repair rounds.
+        exhaustive = cb.raw.n_coded > 2 and cb.raw.max_length <= cb.raw.min_length + 1
+        if exhaustive:
+            mine_map = torch.arange(32, dtype=torch.uint8)  # a rank without blocks passes the start on
+            if active:
+                m, _ = self.ctx.decode_range_maps(cb, stream, begin, end, first_bit if lo_b == 0 else -1)
+                mine_map = torch.tensor(list(m), dtype=torch.uint8)
+            all_maps = torch.zeros(world * 32, dtype=torch.uint8, device=self.coll_device)
+            dist.all_gather_into_tensor(all_maps, mine_map.to(self.coll_device), group=self.group)
+            maps = all_maps.view(world, 32).cpu().numpy()
+            s_in = first_bit
+            for q in range(r):
+                s_in = int(maps[q, s_in])
+            if active:
+                info = self.ctx.decode_range_resolve(s_in)
+        elif active:
             info = self.ctx.decode_range_sync(cb, stream, begin, end, first_bit if lo_b == 0 else -1)
         table = torch.zeros(world * 3, dtype=torch.int64, device=self.coll_device)
         mine = torch.zeros(3, dtype=torch.int64, device=self.coll_device)

@@ -220,6 +220,19 @@ int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const void *d_range
 /* Write the first max_symbols symbols of the range synchronised last into d_out. */
 int et_decode_range_write(et_ctx *ctx, uint64_t max_symbols, void *d_out, size_t cap, size_t *out_len);
 
+/* The same split for codes that do NOT self-synchronise (near-fixed-length ones; SURVEY
+ * §8e's "fall back" case), where run-ins find nothing: et_decode_range_maps computes, for
+ * every bit offset p < *n_starts (= the longest code length, <= 32) at which the range's
+ * first codeword might begin, the offset map[p] at which decoding leaves the range
+ * (exhaustive synchronisation: one walk per offset, maps composed per block and per 256
+ * blocks on the GPU, the last level on the host).  in_start_bit >= 0: the start is known
+ * (the stream's first range), every entry is that start's exit.  The ranks exchange their
+ * 32-byte maps, chain them from the stream's start, and call et_decode_range_resolve with
+ * the start that reaches them; et_decode_range_write then works as above. */
+int et_decode_range_maps(et_ctx *ctx, const et_codebook *cb, const void *d_range, size_t range_bytes, size_t tail_bytes,
+                         int32_t in_start_bit, uint8_t map[32], uint32_t *n_starts);
+int et_decode_range_resolve(et_ctx *ctx, uint32_t in_start_bit, et_range_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,6 +201,53 @@ def test_cold_decode_virtual_ranks(ranks, res_files):
             c.close()
 
 
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_cold_decode_exhaustive_virtual_ranks(ranks):
+    """et_decode_range_maps / _resolve: a stream of near-fixed-length codes (uniform alphabet:
+    nothing to re-synchronise on) cut into block ranges, each on its own et_ctx; the 32-byte
+    start->exit maps are chained by hand as sharded.decode_cold does after its all-gather."""
+    import torch
+
+    import entreepy_amd as E
+    from oracle import oracle as O
+
+    for data in (corpus.uniform(900_001, 31, 1, 256), corpus.uniform(500_000, 32, 10, 10 + 100)):
+        et = O.encode(data)
+        comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy()).cuda()
+        cb, n_symbols, body_off = E.parse_header(et[4:])
+        ptr = comp.data_ptr() + body_off
+        base_off, first_bit = body_off - (ptr & 3), (ptr & 3) * 8
+        stream = comp[base_off:]
+        n_blocks = (stream.numel() + 8191) // 8192
+        ctxs, maps, spans = [], [], []
+        try:
+            for r in range(ranks):
+                lo, hi = r * n_blocks // ranks, (r + 1) * n_blocks // ranks
+                c = E.Context(0)
+                c.use_torch_stream()
+                begin, end = lo * 8192, min(hi * 8192, stream.numel())
+                m, n_starts = c.decode_range_maps(cb, stream, begin, end, first_bit if lo == 0 else -1)
+                assert n_starts == cb.raw.max_length
+                ctxs.append(c)
+                maps.append(m)
+                spans.append((begin, end))
+            out, first, s_in = [], 0, first_bit
+            for c, m in zip(ctxs, maps):
+                inf = c.decode_range_resolve(s_in)
+                assert inf["start_bit"] == s_in and inf["exit_bit"] == m[s_in]
+                s_in = m[s_in]
+                take = max(0, min(inf["n_symbols"], n_symbols - first))
+                buf = torch.empty(inf["n_symbols"] + 64, dtype=torch.uint8, device="cuda")
+                k = c.decode_range_write(take, buf)
+                torch.cuda.synchronize()
+                out.append(buf[:k].cpu().numpy())
+                first += inf["n_symbols"]
+            assert np.concatenate(out).tobytes() == O.decode(et[4:])
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 def test_cold_decode_over_rccl_world_size_1(ctx):
     import torch
     import torch.distributed as dist
@@ -213,14 +260,15 @@ def test_cold_decode_over_rccl_world_size_1(ctx):
         port = s.getsockname()[1]
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        data = corpus.text_like(1_500_000, 71)
-        et = O.encode(data)
-        comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy()).cuda()
-        dec = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
-        codec = sharded.ShardedCodec(ctx, dist.group.WORLD, torch.device("cuda", 0))
-        m, first = codec.decode_cold(comp, dec)
-        torch.cuda.synchronize()
-        assert first == 0 and m == data.size and dec[:m].cpu().numpy().tobytes() == data.tobytes()
+        # text: run-in synchronisation; uniform 200-symbol stream: the exhaustive map exchange
+        for data in (corpus.text_like(1_500_000, 71), corpus.uniform(700_000, 72, 1, 201)):
+            et = O.encode(data)
+            comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy()).cuda()
+            dec = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+            codec = sharded.ShardedCodec(ctx, dist.group.WORLD, torch.device("cuda", 0))
+            m, first = codec.decode_cold(comp, dec)
+            torch.cuda.synchronize()
+            assert first == 0 and m == data.size and dec[:m].cpu().numpy().tobytes() == data.tobytes()
     finally:
         dist.destroy_process_group()
 

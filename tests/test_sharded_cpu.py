@@ -96,6 +96,22 @@ class OracleBackend:
         self._range_syms = syms
         return {"start_bit": start, "exit_bit": p - end * 8, "n_symbols": len(syms), "sweeps": 1}
 
+    def decode_range_maps(self, cb, stream, begin, end, in_start_bit=-1):
+        # exit of the range for every start offset (emulates et_decode_range_maps)
+        self._maps_args = (cb, stream, begin, end)
+        n_starts = int(cb.length.max())
+        m = [0] * 32
+        for p in range(32):
+            if in_start_bit >= 0:
+                m[p] = self.decode_range_sync(cb, stream, begin, end, in_start_bit)["exit_bit"]
+            elif p < n_starts:
+                m[p] = self.decode_range_sync(cb, stream, begin, end, p)["exit_bit"]
+        return bytes(m), n_starts
+
+    def decode_range_resolve(self, in_start_bit):
+        cb, stream, begin, end = self._maps_args
+        return self.decode_range_sync(cb, stream, begin, end, in_start_bit)
+
     def decode_range_write(self, max_symbols, out):
         take = self._range_syms[:max_symbols]
         out[: len(take)] = torch.tensor(take, dtype=torch.uint8)
@@ -168,14 +184,18 @@ def test_plan_shards_offsets():
         assert sharded.owned_words(starts, r)[1] == sharded.owned_words(starts, r + 1)[0]
 
 
-def _cold_worker(rank, world, port, n, q):
+def _cold_data(n, kind):
+    return corpus.text_like(n, 78) if kind == "text" else corpus.uniform(n, 79, 1, 1 + 200)
+
+
+def _cold_worker(rank, world, port, n, q, kind="text"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from entreepy_amd import sharded
 
-        data = corpus.text_like(n, 78)
+        data = _cold_data(n, kind)
         et = O.encode(data)
         comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy())
         codec = sharded.ShardedCodec(OracleBackend(), dist.group.WORLD, torch.device("cpu"))
@@ -186,22 +206,24 @@ def _cold_worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_cold_decode_across_ranks(world):
+@pytest.mark.parametrize("world,kind", [(2, "text"), (3, "text"), (3, "flat")])
+def test_cold_decode_across_ranks(world, kind):
     """sharded.decode_cold over gloo: block ranges, run-in starts, the (start, exit,
-    symbols) all-gather and the repair round; pieces concatenate to the input."""
-    n = 60000  # ~35 KB of body: 5 blocks of 8 KiB
+    symbols) all-gather and the repair round; pieces concatenate to the input.  "flat": a
+    200-symbol uniform stream (7- and 8-bit codes only) takes the exhaustive exchange --
+    per-rank start->exit maps, all-gathered and chained."""
+    n = 60000 if kind == "text" else 30000  # ~35 KB / ~29 KB of body: 4-5 blocks of 8 KiB
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cold_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_cold_worker, args=(r, world, port, n, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    data = corpus.text_like(n, 78).tobytes()
+    data = _cold_data(n, kind).tobytes()
     pos = 0
     for rank, first, piece in got:
         assert first == pos
