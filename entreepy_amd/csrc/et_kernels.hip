@@ -6,11 +6,15 @@
 //   encode.zig:308-313 -> k_tile_bits, k_scan_local/_finish       "K2" (the serial
 //                         bits_written counter turned into a scan over tiles)
 //   encode.zig:303-315 -> k_encode_tiles / k_encode_tiles_long    "K4"
-//   decode.zig:143-203 -> k_dec_sync, k_scan_*, k_dec_write       "D1..D3"
-//                         k_dec_maps, k_dec_compose, k_dec_chain, k_dec_resolve: the
-//                         bounded fallback for codes that do not self-synchronise
+//   decode.zig:143-203 -> "D1..D3": k_dec_sync_reg2 (first sweep, 512-bit lanes in registers),
+//                         k_dec_check + k_dec_sync_reg<false> (repair on a worklist),
+//                         k_scan_* (+ verification), k_dec_write_reg; the LDS-window
+//                         kernels k_dec_sync / k_dec_write for the stream's first and last
+//                         blocks; k_dec_maps[_reg], k_dec_compose, k_dec_chain,
+//                         k_dec_resolve[_reg]: the bounded fallback for codes that do
+//                         not self-synchronise
 //
-// Geometry shared by every kernel: workgroups of 256 threads (4 wavefronts of 64).
+// Geometry: workgroups of 256 threads (4 wavefronts of 64); K1 uses 512 on one set of counters.
 // Encode side: a "round" is 4 KiB of input, one 16-byte load per lane, fully
 // coalesced; a "tile" is 1..16 consecutive rounds and is the unit for which K1
 // leaves a 256-bin histogram and K4 gets a start bit offset.
