@@ -404,3 +404,19 @@ def test_heavily_skewed_streams(ctx, p_common):
     rare = rng.random(n) > p_common
     data[rare] = rng.integers(0, 200, size=int(rare.sum()), dtype=np.uint8)
     _roundtrip(ctx, data)
+
+
+@pytest.mark.parametrize("config", ["2-text-5M", "3-text-100M"])
+def test_baseline_configs_bit_exact(ctx, config):
+    """BASELINE.json configs 2 and 3 at their full sizes (the corpora do not exist
+    offline, so Midsummer tiled to 5 458 199 B and 10^8 order-0 samples of its distribution,
+    seed 0x5EED0003): the GPU .et image is the oracle's, byte for byte, and decodes back.
+    (Config 1 is test_reference_fixtures, config 4 the bench and
+    test_large_stream_properties, config 5 tests/config5_check.py.)"""
+    O = _oracle()
+    data = corpus.tiled_midsummer(5_458_199) if config.startswith("2") else corpus.text_like(100_000_000, 0x5EED0003)
+    want = O.encode(data)
+    got = ctx.encode(data)
+    assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
+    back = ctx.decode(got[4:])
+    assert len(back) == data.size and hashlib.sha256(back).digest() == hashlib.sha256(data.tobytes()).digest()
