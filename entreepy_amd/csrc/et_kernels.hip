@@ -1211,7 +1211,7 @@ __device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32
             "s_mov_b64 exec, %[sv]"                                                    \
             : [x] "+v"(X), [e] "+v"(e), [t] "=&v"(t_), [sv] "=&s"(saved_)              \
             : [hi] "v"(hi_), [lo] "v"(lo_), [sh] "s"(idx_shift), [base] "v"(steps_lds), [fl] "s"(floor_) \
-            : "vcc");                                                                  \
+            : "vcc", "scc");                                                           \
     }
 #else
 #define ET_SW_LOOP(hi_, lo_, floor_) while (ET_F >= (floor_)) ET_SW_STEP(hi_, lo_)
@@ -1801,9 +1801,15 @@ __device__ __forceinline__ void walk_write(const StepWalk &sw, const uint8_t *sy
             X -= 1; /* no code: one bit on, no symbol */                                                               \
         }                                                                                                              \
     }
+// (A hand-written version of this loop like ET_SW_LOOP, with an SDWA byte compare on the
+// position field, was 8 VALU + 2 SALU per step instead of 9 + 3 -- and hung one test in one
+// ordering of the suite: lanes left the loop at the wrong time now and then, most likely the
+// SDWA compare's VCC reaching the s_and a cycle late.  Not worth it for a kernel bound by the
+// LDS pipe; the compiler's loop stays.)
+#define ET_WW_LOOP(hi_, lo_, floor_) while (ET_F >= (floor_)) ET_WW_STEP(hi_, lo_)
 #define ET_WW_WORD(hi_, lo_)                                                          \
     for (;;) {                                                                        \
-        while (ET_F >= 64) ET_WW_STEP(hi_, lo_)                                       \
+        ET_WW_LOOP(hi_, lo_, 64u)                                                     \
         if (ET_F >= 32) break;                                                        \
         X -= WSTEP_ESCAPE;                                                            \
         ET_WW_SLOW(hi_, lo_)                                                          \
@@ -1818,7 +1824,7 @@ __device__ __forceinline__ void walk_write(const StepWalk &sw, const uint8_t *sy
     ET_WW_WORD(W[9], W[10])
     ET_WW_WORD(W[10], W[11])
     for (;;) {  // the last word: two-symbol steps while step_bits bits are left, then one codeword at a time
-        while (ET_F >= sw.multi_floor) ET_WW_STEP(W[11], W[12])
+        ET_WW_LOOP(W[11], W[12], sw.multi_floor)
         if (ET_F >= 32) break;
         X -= WSTEP_ESCAPE;
         ET_WW_SLOW(W[11], W[12])
@@ -1834,6 +1840,7 @@ __device__ __forceinline__ void walk_write(const StepWalk &sw, const uint8_t *sy
         }
     }
 #undef ET_WW_WORD
+#undef ET_WW_LOOP
 #undef ET_WW_SLOW
 #undef ET_WW_STEP
 #undef ET_PUT
