@@ -14,6 +14,7 @@
 
 #include "et_io.h"
 #include "et_kernels.h"
+#include "et_tables.h"
 
 #include <hip/hip_runtime.h>
 
@@ -639,157 +640,6 @@ extern "C" int et_encode_fd(et_ctx *ctx, int in_fd, int out_fd, size_t *in_len, 
 // ---------------------------------------------------------------------------------
 namespace {
 
-// First-level table indexed by the next lut_bits bits: the symbol whose code is a
-// prefix of the index and, when a second whole code also fits in the remaining bits,
-// that one too (layout: et_kernels.h LUT_*).  Codes longer than lut_bits go to a short
-// list searched linearly (they are the rare symbols by construction).
-struct HostDecodeTables {
-    uint32_t lut_bits, n_long, sub_bits, n_sub;
-};
-
-void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t max_syms, uint32_t *lut, uint32_t *longc, uint16_t *sub,
-                         HostDecodeTables *out) {
-    const uint32_t k = cb->max_length < lut_bits_max ? (cb->max_length ? cb->max_length : 1) : lut_bits_max;
-    const uint32_t n = 1u << k;
-    const uint32_t sub_bits = cb->max_length > k ? (cb->max_length - k < et::DEC_SUB_BITS_MAX ? cb->max_length - k : et::DEC_SUB_BITS_MAX) : 0;
-    std::vector<uint16_t> single(n, 0);  // (len << 8) | sym of the code that prefixes the index
-    std::vector<int> sub_of(n, -1);      // second-level table of a first-level index
-    uint32_t nl = 0, n_sub = 0;
-    for (int s = 0; s < 256; ++s) {
-        const uint32_t len = cb->length[s];
-        if (!len) continue;
-        const uint32_t code = cb->data[s];
-        const uint32_t meta = (len << 8) | static_cast<uint32_t>(s);
-        if (len <= k) {
-            const uint32_t first = code << (k - len), span = 1u << (k - len);
-            for (uint32_t i = 0; i < span; ++i) single[first + i] = static_cast<uint16_t>(meta);
-        } else {
-            longc[2 * nl] = code << (32 - len);
-            longc[2 * nl + 1] = meta;
-            ++nl;
-            const uint32_t prefix = code >> (len - k), rest_bits = len - k;
-            if (sub_of[prefix] < 0 && n_sub < et::DEC_SUB_TABLES_MAX) {
-                sub_of[prefix] = static_cast<int>(n_sub);
-                std::memset(sub + (static_cast<size_t>(n_sub) << sub_bits), 0, sizeof(uint16_t) << sub_bits);
-                ++n_sub;
-            }
-            if (sub_of[prefix] >= 0 && rest_bits <= sub_bits) {
-                const uint32_t rest = code & ((1u << rest_bits) - 1u);
-                uint16_t *t = sub + (static_cast<size_t>(sub_of[prefix]) << sub_bits);
-                const uint32_t first = rest << (sub_bits - rest_bits), span = 1u << (sub_bits - rest_bits);
-                for (uint32_t i = 0; i < span; ++i) t[first + i] = static_cast<uint16_t>(meta);
-            }
-        }
-    }
-    for (uint32_t v = 0; v < n; ++v) {
-        // greedily take whole codes out of the k-bit index: up to three symbols
-        uint32_t entry = 0, used = 0, cnt = 0;
-        while (cnt < max_syms) {
-            const uint32_t rest = (v << used) & (n - 1);  // the remaining k - used bits, left-aligned in k
-            const uint32_t e = single[rest], len = e >> 8;
-            if (!len || used + len > k) break;
-            entry |= (e & 0xffu) << (8 * cnt);
-            used += len;
-            ++cnt;
-        }
-        if (cnt) entry |= (used << et::LUT_LEN_SHIFT) | (cnt << et::LUT_N_SHIFT);
-        else if (sub_of[v] >= 0) entry = static_cast<uint32_t>(sub_of[v]) | (1u << et::LUT_SUB_SHIFT);
-        lut[v] = entry;
-    }
-    out->lut_bits = k;
-    out->n_long = nl;
-    out->sub_bits = sub_bits;
-    out->n_sub = n_sub;
-}
-
-// Step table of k_dec_sync_reg (et_kernels.h STEP_*): index = the next k bits, entry =
-// what a lookup adds to the walk state; second-level tables for the codes longer than k
-// follow it.  Returns k.
-uint32_t build_step_table(const et_codebook *cb, uint32_t bits_max, uint32_t *steps, uint32_t *sub_bits_out, uint32_t *n_sub_out) {
-    const uint32_t k = cb->max_length < bits_max ? (cb->max_length ? cb->max_length : 1) : bits_max;
-    const uint32_t n = 1u << k;
-    const uint32_t sub_bits = cb->max_length > k ? (cb->max_length - k < et::DEC_SUB_BITS_MAX ? cb->max_length - k : et::DEC_SUB_BITS_MAX) : 0;
-    uint32_t *ssub = steps + n;
-    std::vector<uint8_t> first(n, 0);  // length of the code that prefixes the index
-    std::vector<uint8_t> table_of(n, 0);  // 1 + second-level table of an index that is the prefix of longer codes
-    uint32_t n_sub = 0;
-    for (int s = 0; s < 256; ++s) {
-        const uint32_t len = cb->length[s];
-        if (!len) continue;
-        if (len <= k) {
-            std::memset(first.data() + (cb->data[s] << (k - len)), static_cast<int>(len), static_cast<size_t>(1) << (k - len));
-            continue;
-        }
-        const uint32_t prefix = cb->data[s] >> (len - k), rest_bits = len - k;
-        if (!table_of[prefix] && n_sub < 15 && ((n_sub + 1) << sub_bits) <= et::DEC_STEP_SUB_WORDS) {
-            std::memset(ssub + (static_cast<size_t>(n_sub) << sub_bits), 0, sizeof(uint32_t) << sub_bits);
-            table_of[prefix] = static_cast<uint8_t>(++n_sub);
-        }
-        if (table_of[prefix] && rest_bits <= sub_bits) {
-            uint32_t *t = ssub + (static_cast<size_t>(table_of[prefix] - 1) << sub_bits);
-            const uint32_t lo = (cb->data[s] & ((1u << rest_bits) - 1u)) << (sub_bits - rest_bits);
-            for (uint32_t i = 0; i < (1u << (sub_bits - rest_bits)); ++i) t[lo + i] = (1u << 16) - len;
-        }
-    }
-    for (uint32_t v = 0; v < n; ++v) {
-        uint32_t used = 0, cnt = 0;
-        for (;;) {
-            const uint32_t len = first[(v << used) & (n - 1)];
-            if (!len || used + len > k) break;
-            used += len;
-            ++cnt;
-        }
-        steps[v] = cnt ? (static_cast<uint32_t>(first[v]) << 28) + (cnt << 16) - used : et::STEP_ESCAPE + (static_cast<uint32_t>(table_of[v]) << 28);
-    }
-    *sub_bits_out = sub_bits;
-    *n_sub_out = n_sub;
-    return k;
-}
-
-// Step table of k_dec_write_reg (et_kernels.h WSTEP_*): as build_step_table, with symbols.
-uint32_t build_write_step_table(const et_codebook *cb, uint32_t bits_max, uint32_t *steps, uint32_t *sub_bits_out, uint32_t *n_sub_out) {
-    const uint32_t k = cb->max_length < bits_max ? (cb->max_length ? cb->max_length : 1) : bits_max;
-    const uint32_t n = 1u << k;
-    const uint32_t sub_bits = cb->max_length > k ? (cb->max_length - k < et::DEC_SUB_BITS_MAX ? cb->max_length - k : et::DEC_SUB_BITS_MAX) : 0;
-    uint32_t *wsub = steps + n;
-    std::vector<uint16_t> first(n, 0);  // (len << 8) | sym of the code that prefixes the index
-    std::vector<uint8_t> table_of(n, 0);
-    uint32_t n_sub = 0;
-    for (int s = 0; s < 256; ++s) {
-        const uint32_t len = cb->length[s];
-        if (!len) continue;
-        if (len <= k) {
-            const uint32_t lo = cb->data[s] << (k - len);
-            for (uint32_t i = 0; i < (1u << (k - len)); ++i) first[lo + i] = static_cast<uint16_t>((len << 8) | static_cast<uint32_t>(s));
-            continue;
-        }
-        const uint32_t prefix = cb->data[s] >> (len - k), rest_bits = len - k;
-        if (!table_of[prefix] && n_sub < 254 && ((n_sub + 1) << sub_bits) <= et::DEC_STEP_SUB_WORDS) {
-            std::memset(wsub + (static_cast<size_t>(n_sub) << sub_bits), 0, sizeof(uint32_t) << sub_bits);
-            table_of[prefix] = static_cast<uint8_t>(++n_sub);
-        }
-        if (table_of[prefix] && rest_bits <= sub_bits) {
-            uint32_t *t = wsub + (static_cast<size_t>(table_of[prefix] - 1) << sub_bits);
-            const uint32_t lo = (cb->data[s] & ((1u << rest_bits) - 1u)) << (sub_bits - rest_bits);
-            for (uint32_t i = 0; i < (1u << (sub_bits - rest_bits)); ++i) t[lo + i] = (static_cast<uint32_t>(s) << 16) | ((1u << 10) - len);
-        }
-    }
-    for (uint32_t v = 0; v < n; ++v) {
-        uint32_t used = 0, cnt = 0, syms = 0;
-        while (cnt < 2) {
-            const uint32_t f = first[(v << used) & (n - 1)], len = f >> 8;
-            if (!len || used + len > k) break;
-            syms |= (f & 0xffu) << (16 + 8 * cnt);
-            used += len;
-            ++cnt;
-        }
-        steps[v] = cnt ? syms | (((cnt << 10) - used) & 0xffffu) : (static_cast<uint32_t>(table_of[v]) << 24) | et::WSTEP_ESCAPE;
-    }
-    *sub_bits_out = sub_bits;
-    *n_sub_out = n_sub;
-    return k;
-}
-
 // Build the decode tables on the host and upload them (one pinned block, one device block,
 // one copy): the step tables of the register-window kernels (k_dec_sync_reg: index
 // step_bits, symbol-free; k_dec_write_reg: index lut_bits_write, two symbols) and ONE set of
@@ -799,6 +649,11 @@ uint32_t build_write_step_table(const et_codebook *cb, uint32_t bits_max, uint32
 // used to be built as well: 12 us of host time per call for kernels that now see three
 // blocks of a stream; near-fixed-length codes, the exhaustive path's domain, rarely fit two
 // codes in an index anyway.)
+using et::HostDecodeTables;
+using et::build_decode_tables;
+using et::build_step_table;
+using et::build_write_step_table;
+
 int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *tb_out, et::DecodeTables *tb_write_out) {
     // one pinned block, one device block, one upload: [first-level x 2 | long lists | second-level (+ lengths) x 2]
     ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "et_tables.h"
+
 namespace et {
 
 constexpr int BLOCK = 256;                    // threads per workgroup: 4 wavefronts of 64
@@ -41,18 +43,6 @@ constexpr uint32_t DEC_FRONT_WORDS = 4;                        // words staged B
 constexpr uint32_t DEC_WARMUP_BITS = DEC_FRONT_WORDS * 32;     // run-in before each subsequence in the first sync sweep
 constexpr uint32_t DEC_STAGED_WORDS = DEC_FRONT_WORDS + DEC_BLOCK_WORDS + DEC_GUARD_WORDS;
 constexpr uint32_t DEC_SDATA_WORDS = (DEC_STAGED_WORDS + (DEC_STAGED_WORDS >> 5) + 4) & ~3u;  // 1 pad word per 32
-constexpr uint32_t DEC_LUT_BITS_MAX = 12;                      // first-level table: at most 4096 x u32 in LDS
-constexpr uint32_t DEC_LUT_BITS_WRITE = 11;                    // write kernels: measured 10 / 11 / 12 -> 0.65 / 0.60 / 0.68 ms at 1 GiB
-// first-level table entry (u32), indexed by the next lut_bits bits: bytes 0..2 = up to
-// three symbols whose codes all fit in the index, bits 24..27 = total length of those
-// codes, bits 28..29 = how many (0: the first code is longer than the table, or no code
-// starts here).  Escape entries (count 0): bit 30 set -> byte 0 is the index of a
-// second-level table of 1 << sub_bits u16 entries ((len << 8) | sym, 0 = not here)
-// indexed by the sub_bits bits that follow the first lut_bits.
-constexpr uint32_t LUT_LEN_SHIFT = 24, LUT_N_SHIFT = 28, LUT_SUB_SHIFT = 30;
-// symbols per entry of the older-format tables: two (k_dec_write stores at most two per step)
-constexpr uint32_t DEC_WRITE_SYMS = 2;
-constexpr uint32_t DEC_SUB_BITS_MAX = 8, DEC_SUB_TABLES_MAX = 16;
 constexpr uint32_t DEC_STAGE_BYTES = 16384;                    // LDS staging of decoded symbols
 
 // Device-resident decode tables (built on the host, et_api.cpp build_decode_tables).
@@ -72,25 +62,6 @@ struct DecodeTables {
     uint32_t n_step_sub;
     const DecodeTables *dev_copy;  // this struct in device memory (slow path of the step walks), or null
 };
-
-// Step table of k_dec_sync_reg (no symbols, only how far a lookup moves the walk).  The
-// walk state X is one u32: bits 0..15 = STEP_BIAS - (bits walked), bits 16..27 = symbols
-// begun, bits 28..31 junk; entry = (len_first << 28) + (n << 16) - len_total is simply
-// ADDED to X (n = all the whole codes inside the index, len_first = length of the first
-// one for single steps).  No code inside the index: STEP_ESCAPE = one "symbol" of
-// STEP_ESCAPE_BITS bits, which throws the lane out of the word loop it is in; the loop's
-// exit test sees how far it flew and resolves the long code: bits 28..31 of the escape
-// entry = 1 + the second-level table (entries (1 << 16) - len, 0 = not here) indexed by the
-// step_sub_bits bits after the index, 0 = no table (tables in global memory, slow).
-constexpr uint32_t DEC_STEP_BITS_MAX = 13, DEC_STEP_BITS_DEFAULT = 12;
-// k_dec_write_reg's table (DecodeTables::steps of the write set) has the same shape with
-// symbols: state X = (stage address << 10) | (WSTEP_BIAS - bits walked); entry = sym2 << 24 |
-// sym1 << 16 | u16((n << 10) - len_total), n <= 2, whose sign-extended low half is added
-// to X; escape = WSTEP_ESCAPE in the low half, 1 + second-level table in bits 24..31;
-// second-level entries sym << 16 | ((1 << 10) - len), 0 = not here.
-constexpr uint32_t WSTEP_BIAS = 992, WSTEP_ESCAPE = (1u << 10) - 64;
-constexpr uint32_t DEC_STEP_SUB_WORDS = 1024;                   // second-level entries, all tables together
-constexpr uint32_t STEP_BIAS = 0x4000, STEP_ESCAPE_BITS = 64, STEP_ESCAPE = (1u << 16) - STEP_ESCAPE_BITS;
 
 // The three-workgroup launches for the stream's first/last blocks take ~25 us each (one
 // block's latency); given a side lane they run beside the big launch instead of after it.

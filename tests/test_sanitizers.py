@@ -63,3 +63,133 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     subprocess.check_call(cmd)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+TABLES_DRIVER = textwrap.dedent(r"""
+    #include "entreepy_hip.h"
+    #include "et_tables.h"
+    #include <cstdio>
+    #include <cstdlib>
+    #include <cstring>
+    #include <vector>
+    // The decode lookup tables (et_tables.cpp) against a brute-force decoder, for random code
+    // tables from the product's own code construction: every first-level entry of every
+    // format, and the second level of every code longer than the index.
+    static uint64_t rng = 0x9E3779B97F4A7C15ull;
+    static uint64_t next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; }
+    static const et_codebook *CB;
+    // the code that prefixes the `avail` bits at the top of w: returns symbol or -1, *len
+    static int first_code(uint32_t w, uint32_t avail, uint32_t *len) {
+        for (int s = 0; s < 256; ++s) {
+            const uint32_t l = CB->length[s];
+            if (!l || l > avail) continue;
+            const uint32_t code = l == 32 ? CB->data[s] : (CB->data[s] & ((1u << l) - 1u));
+            if ((w >> (32 - l)) == code) { *len = l; return s; }
+        }
+        return -1;
+    }
+    #define FAIL(...) do { std::printf(__VA_ARGS__); std::printf(" (it %d)\n", it); return 1; } while (0)
+    int main() {
+        std::vector<uint32_t> lut(1u << et::DEC_LUT_BITS_MAX), longc(512), steps((1u << et::DEC_STEP_BITS_MAX) + et::DEC_STEP_SUB_WORDS + 8);
+        std::vector<uint16_t> sub((et::DEC_SUB_TABLES_MAX << et::DEC_SUB_BITS_MAX) + 64);
+        int checked = 0;
+        for (int it = 0; it < 700; ++it) {
+            uint64_t hist[256] = {0};
+            const int k = 1 + next() % 256, mode = it % 4;
+            for (int i = 0; i < k; ++i) hist[next() % 256] = mode == 0 ? 1 + next() % 3 : mode == 1 ? 1 + next() % 100000 : mode == 2 ? 1ull << (next() % 30) : 7;
+            et_codebook cb;
+            if (et_build_codebook(hist, &cb) != ET_OK || cb.n_coded == 0 || cb.max_length > 32) continue;
+            CB = &cb;
+            ++checked;
+            // --- sync step table, several index widths
+            const uint32_t widths[3] = {12, 13, 9};
+            for (uint32_t want : widths) {
+                uint32_t sb = 0, ns = 0;
+                const uint32_t K = et::build_step_table(&cb, want, steps.data(), &sb, &ns);
+                if (K > want || K > cb.max_length || (ns << sb) > et::DEC_STEP_SUB_WORDS) FAIL("step table shape");
+                for (uint32_t v = 0; v < (1u << K); ++v) {
+                    uint32_t used = 0, cnt = 0, first = 0, l = 0;
+                    while (used < K && first_code(v << (32 - K) << used, K - used, &l) >= 0) { if (!cnt) first = l; used += l; ++cnt; }
+                    const uint32_t e = steps[v];
+                    if (cnt) { if (e != (first << 28) + (cnt << 16) - used) FAIL("step entry %u", v); }
+                    else if ((e & 0x0fffffffu) != et::STEP_ESCAPE) FAIL("escape entry %u", v);
+                }
+                for (int s = 0; s < 256; ++s) {
+                    const uint32_t l = cb.length[s];
+                    if (l <= K) continue;
+                    const uint32_t code = l == 32 ? cb.data[s] : (cb.data[s] & ((1u << l) - 1u));
+                    const uint32_t e = steps[code >> (l - K)], t = e >> 28;
+                    if ((e & 0x0fffffffu) != et::STEP_ESCAPE) FAIL("long code %d has no escape", s);
+                    if (t && l - K <= sb) {
+                        const uint32_t rest = (code & ((1u << (l - K)) - 1u)) << (sb - (l - K)) | (static_cast<uint32_t>(next()) & ((1u << (sb - (l - K))) - 1u));
+                        if (t > ns || steps[(1u << K) + ((t - 1) << sb) + rest] != (1u << 16) - l) FAIL("second level of %d", s);
+                    }
+                }
+            }
+            // --- write step table
+            {
+                uint32_t sb = 0, ns = 0;
+                const uint32_t K = et::build_write_step_table(&cb, 11, steps.data(), &sb, &ns);
+                if ((ns << sb) > et::DEC_STEP_SUB_WORDS) FAIL("write table shape");
+                for (uint32_t v = 0; v < (1u << K); ++v) {
+                    uint32_t used = 0, cnt = 0, syms = 0, l = 0;
+                    int s;
+                    while (cnt < 2 && used < K && (s = first_code(v << (32 - K) << used, K - used, &l)) >= 0) { syms |= static_cast<uint32_t>(s) << (16 + 8 * cnt); used += l; ++cnt; }
+                    const uint32_t e = steps[v];
+                    if (cnt) { if (e != (syms | (((cnt << 10) - used) & 0xffffu))) FAIL("write entry %u", v); }
+                    else if ((e & 0xffffu) != et::WSTEP_ESCAPE) FAIL("write escape %u", v);
+                }
+                for (int s = 0; s < 256; ++s) {
+                    const uint32_t l = cb.length[s];
+                    if (l <= K) continue;
+                    const uint32_t code = l == 32 ? cb.data[s] : (cb.data[s] & ((1u << l) - 1u));
+                    const uint32_t e = steps[code >> (l - K)], t = e >> 24;
+                    if ((e & 0xffffu) != et::WSTEP_ESCAPE) FAIL("write: long code %d has no escape", s);
+                    if (t && l - K <= sb) {
+                        const uint32_t rest = (code & ((1u << (l - K)) - 1u)) << (sb - (l - K));
+                        if (t > ns || steps[(1u << K) + ((t - 1) << sb) + rest] != ((static_cast<uint32_t>(s) << 16) | ((1u << 10) - l))) FAIL("write second level of %d", s);
+                    }
+                }
+            }
+            // --- older format
+            {
+                et::HostDecodeTables ht;
+                et::build_decode_tables(&cb, 11, et::DEC_WRITE_SYMS, lut.data(), longc.data(), sub.data(), &ht);
+                const uint32_t K = ht.lut_bits;
+                for (uint32_t v = 0; v < (1u << K); ++v) {
+                    uint32_t used = 0, cnt = 0, syms = 0, l = 0;
+                    int s;
+                    while (cnt < et::DEC_WRITE_SYMS && used < K && (s = first_code(v << (32 - K) << used, K - used, &l)) >= 0) { syms |= static_cast<uint32_t>(s) << (8 * cnt); used += l; ++cnt; }
+                    const uint32_t e = lut[v];
+                    if (cnt && e != (syms | (used << et::LUT_LEN_SHIFT) | (cnt << et::LUT_N_SHIFT))) FAIL("lut entry %u", v);
+                    if (!cnt && ((e >> et::LUT_N_SHIFT) & 3u)) FAIL("lut escape %u", v);
+                }
+                uint32_t n_long = 0;
+                for (int s = 0; s < 256; ++s) n_long += cb.length[s] > K;
+                if (n_long != ht.n_long) FAIL("long list length");
+                for (uint32_t i = 0; i < ht.n_long; ++i) {
+                    const uint32_t meta = longc[2 * i + 1], l = meta >> 8, s = meta & 0xffu;
+                    const uint32_t code = l == 32 ? cb.data[s] : (cb.data[s] & ((1u << l) - 1u));
+                    if (cb.length[s] != l || longc[2 * i] != code << (32 - l)) FAIL("long list entry %u", i);
+                }
+            }
+        }
+        std::printf(checked > 300 ? "ok\n" : "too few code tables\n");
+        return 0;
+    }
+""")
+
+
+@pytest.mark.skipif(subprocess.run(["which", "g++"], capture_output=True).returncode != 0, reason="g++ missing")
+def test_decode_table_builders_under_asan_ubsan(tmp_path):
+    """et_tables.cpp (the four lookup-table formats of the decode kernels) against a
+    brute-force decoder, under AddressSanitizer + UBSan."""
+    src = tmp_path / "tables_driver.cpp"
+    src.write_text(TABLES_DRIVER)
+    exe = tmp_path / "tables_driver"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           f"-I{ROOT}/include", f"-I{ROOT}/entreepy_amd/csrc", str(src), f"{ROOT}/entreepy_amd/csrc/et_tables.cpp",
+           f"{ROOT}/entreepy_amd/csrc/et_codebook.cpp", "-o", str(exe)]
+    subprocess.check_call(cmd)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr

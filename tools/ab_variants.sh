@@ -10,7 +10,7 @@ if [ "$mode" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Iinclude --offload-arch=gfx950 $flags -shared -o build/variants/lib_$name.so \
-      entreepy_amd/csrc/et_kernels.hip entreepy_amd/csrc/et_api.cpp entreepy_amd/csrc/et_codebook.cpp entreepy_amd/csrc/et_io.cpp -lpthread 2>&1 | grep -E "error" || true
+      entreepy_amd/csrc/et_kernels.hip entreepy_amd/csrc/et_api.cpp entreepy_amd/csrc/et_codebook.cpp entreepy_amd/csrc/et_io.cpp entreepy_amd/csrc/et_tables.cpp -lpthread 2>&1 | grep -E "error" || true
     echo "built $name ($flags)"
   done
 else
