@@ -74,7 +74,7 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=int(os.environ.get("ET_BENCH_BYTES", 1 << 30)), help="text bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
