@@ -762,15 +762,16 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     bool wrote = false, write_ticket_zero = false;
     auto scan_and_total = [&](bool verify) -> int {
         et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
-                            verify ? sub_state : nullptr, blk_exit, flag + 2);
+                            verify ? sub_state : nullptr, blk_exit, flag + 2, first_bit);
         ET_HIP(hipGetLastError());
         ET_HIP(hipMemcpyAsync(h_flags, flag, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
         return ET_OK;
     };
-    auto write_symbols = [&](uint64_t clamp) -> int {
+    auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
+        // speculative: the kernel itself looks at the sweeps' flags and does nothing if the state is not final
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
-                             write_ticket_zero);
+                             write_ticket_zero, speculative ? flag : nullptr);
         write_ticket_zero = false;
         ET_HIP(hipGetLastError());
         return ET_OK;
@@ -792,7 +793,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ET_TRY(scan_and_total(true));
         record(ctx, EV_DEC + 2);
         if (can_speculate) {
-            ET_TRY(write_symbols(n_symbols));
+            ET_TRY(write_symbols(n_symbols, true));
             wrote = true;
         }
         ET_HIP(hipEventSynchronize(ctx->ev_flags));  // not the stream: the write kernel keeps running while the caller moves on
@@ -836,7 +837,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     const uint64_t decodable = static_cast<uint64_t>(h_flags[12]) | (static_cast<uint64_t>(h_flags[13]) << 32);
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
-    if (n_out && !wrote) ET_TRY(write_symbols(n_out));
+    if (n_out && !wrote) ET_TRY(write_symbols(n_out, false));
     record(ctx, EV_DEC + 3);
     *out_len = static_cast<size_t>(n_out);
     if (ctx->timing) {

@@ -93,10 +93,10 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
                            uint32_t *blk_count);
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
                      unsigned long long *blk_off, unsigned long long *total_copy = nullptr, const uint32_t *verify_state = nullptr,
-                     const uint32_t *verify_exit = nullptr, uint32_t *verify_flag = nullptr);
+                     const uint32_t *verify_exit = nullptr, uint32_t *verify_flag = nullptr, uint32_t verify_first = 0xffffffffu);
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr,
-                      bool ticket_is_zero = false);
+                      bool ticket_is_zero = false, const uint32_t *void_flags = nullptr);
 
 }  // namespace et

@@ -245,11 +245,16 @@ __global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict_
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out,
                                                      unsigned long long *__restrict__ group_sum, const uint32_t *__restrict__ verify_state,
-                                                     const uint32_t *__restrict__ verify_exit, uint32_t *__restrict__ verify_flag) {
+                                                     const uint32_t *__restrict__ verify_exit, uint32_t *__restrict__ verify_flag,
+                                                     uint32_t verify_first) {
     __shared__ unsigned long long wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i = blockIdx.x * 1024 + tid;
-    if (verify_state && i > 0 && i < n && (verify_state[static_cast<uint64_t>(i) * BLOCK] & 0xffu) != verify_exit[i - 1]) *verify_flag = 1;
+    // (block 0 must have started at verify_first, the stream's known first bit; 0xffffffff: not checked)
+    if (verify_state && i < n) {
+        const uint32_t want = i > 0 ? verify_exit[i - 1] : verify_first;
+        if (want != 0xffffffffu && (verify_state[static_cast<uint64_t>(i) * BLOCK] & 0xffu) != want) *verify_flag = 1;
+    }
     const unsigned long long x = (i < n) ? static_cast<unsigned long long>(in[i]) : 0ull;
     const unsigned long long inc = wave_inclusive_scan64(x);
     if (lane == 63) wsum[wave] = inc;
@@ -1851,7 +1856,15 @@ __device__ __forceinline__ void walk_write(const StepWalk &sw, const uint8_t *sy
 __global__ __launch_bounds__(BLOCK) ET_WRITE_ATTR void k_dec_write_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                          StepTableArgs ta, const uint8_t *__restrict__ sym_len_g, const uint32_t *__restrict__ sub_state,
                                                          const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
-                                                         uint8_t *__restrict__ out, uint32_t *__restrict__ ticket) {
+                                                         uint8_t *__restrict__ out, uint32_t *__restrict__ ticket,
+                                                         const uint32_t *__restrict__ void_flags) {
+    // A speculative launch (enqueued before the host has seen the sweeps' flags) does nothing
+    // when the synchronisation did not settle: void_flags[1] = blocks that gave up (their first
+    // subsequence carries the start marker 0xff, not a bit offset), void_flags[2] = the
+    // verification failed.  The host discards this launch's output in both cases and writes
+    // again once the state is final.  (Walking from the marker would send the packed walk state's
+    // address field through the LDS tables: a stream with long runs of one code hung this kernel.)
+    if (void_flags && (void_flags[1] | void_flags[2])) return;
     // LDS: step table, its second-level tables | code lengths | scratch | stage
     uint32_t *wsteps = reinterpret_cast<uint32_t *>(dec_smem_raw);
     const uint32_t step_words = ta.words;
@@ -1879,7 +1892,7 @@ __global__ __launch_bounds__(BLOCK) ET_WRITE_ATTR void k_dec_write_reg(const uin
             if (o0 >= n_symbols) break;  // pad bits decoded past the declared length; offsets only grow from here
             const uint64_t sub_g = b * BLOCK + tid;
             const uint32_t st = sub_state[sub_g];
-            const uint32_t start = st & 0xffu, count = st >> 16;
+            const uint32_t start = st & 31u, count = st >> 16;  // (a start is < 32 in a settled state; masked so that nothing else can reach the walk)
             uint32_t W[RW_WORDS];
             load_window<false>(W, words, sub_g);
             uint32_t block_total;
@@ -1922,7 +1935,9 @@ __global__ __launch_bounds__(BLOCK) ET_WRITE_ATTR void k_dec_write_reg(const uin
 __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict__ words, uint64_t n_bytes, uint64_t n_subs,
                                                      uint32_t n_blocks, DecodeTables tb, const uint32_t *__restrict__ sub_state,
                                                      const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
-                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ ticket, uint32_t special_only) {
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ ticket, uint32_t special_only,
+                                                     const uint32_t *__restrict__ void_flags) {
+    if (void_flags && (void_flags[1] | void_flags[2])) return;  // see k_dec_write_reg
     const DecodeSmem m = carve_decode_smem<false>(tb);
     const int tid = threadIdx.x;
     stage_tables(m, tb);
@@ -2052,7 +2067,7 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
     if (grid > MAX_GRID) grid = MAX_GRID;
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
     const uint32_t groups = (n_tiles + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr));
+    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), 0xffffffffu);
     hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr));
 }
 
@@ -2200,15 +2215,16 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
                      unsigned long long *blk_off, unsigned long long *total_copy, const uint32_t *verify_state, const uint32_t *verify_exit,
-                     uint32_t *verify_flag) {
+                     uint32_t *verify_flag, uint32_t verify_first) {
     const uint32_t groups = (n_blocks + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag);
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag, verify_first);
     hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy);
 }
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
-                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero) {
+                      const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero,
+                      const uint32_t *void_flags) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
     const size_t smem = decode_smem_bytes(tb, true, false);
@@ -2216,13 +2232,13 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     if (use_reg_kernels(n_blocks)) {
         const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
         fork_mark(side, stream);
-        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket);
+        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket, void_flags);
         const hipStream_t special = fork_special(side, stream);
-        hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u);
+        hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u, void_flags);
         join_special(side, stream);
         return;
     }
-    hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 0u);
+    hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 0u, void_flags);
 }
 
 }  // namespace et

@@ -394,6 +394,30 @@ def test_decode_fuzzed_bodies_match_the_oracle(ctx):
         assert ctx.decode(bytes(good)) == want, f"trial {trial} kind {kind}"
 
 
+@pytest.mark.parametrize("where", ["front", "middle", "several"])
+def test_runs_of_one_long_code_do_not_settle(ctx, where):
+    """Long runs of 0xff / 0x00 inside a text stream decode as one long code repeated: a wrong
+    start never re-synchronises there, blocks hit the trip cap (start marker 0xff), the
+    speculative write must not act on that state (it once walked from the marker and
+    overwrote its own LDS tables: an intermittent hang) and the result must still be the
+    oracle's -- also when the run covers the stream's FIRST block, whose start the
+    verification has to check against the known first bit."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    rng = np.random.default_rng(11)
+    text = corpus.text_like(700_000, 41)
+    good = bytearray(O.encode(text)[4:])
+    _, _, off = E.parse_header(bytes(good))
+    spans = {"front": [(off, 30_000)], "middle": [(off + 150_000, 40_000)],
+             "several": [(off + 20_000, 9_000), (off + 100_000, 25_000), (off + 300_000, 17_000)]}[where]
+    for i, (a, ln) in enumerate(spans):
+        good[a : a + ln] = (b"\xff" if i % 2 == 0 else b"\x00") * ln
+    want = O.decode(bytes(good))
+    for _ in range(6):  # the failure was timing dependent
+        assert ctx.decode(bytes(good)) == want
+
+
 @pytest.mark.parametrize("p_common", [0.9, 0.99, 0.999])
 def test_heavily_skewed_streams(ctx, p_common):
     """One symbol dominates: 1-bit codes, up to 65536 symbols per 8 KiB block (the write
