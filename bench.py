@@ -56,6 +56,36 @@ def cpu_baseline(sample_u8, budget_s=14.0):
     }
 
 
+def cpu_baseline_parallel(sample_u8, threads, budget_s=8.0):
+    """SURVEY.md 8d's second CPU figure: the fast chunk-parallel CPU variant
+    (oracle/et_cpu_fast.c, one chunk per thread).  Default thread count: this process's
+    CPU share of the GPU box (16 host cores per GPU on the pool), not the whole host."""
+    from oracle import cpu_fast as F
+
+    cores = threads or min(len(os.sched_getaffinity(0)), 16)
+    probe = sample_u8[: 32 << 20]
+    t = time.perf_counter()
+    F.decode(F.encode(probe, cores)[4:], cores)
+    per_byte = (time.perf_counter() - t) / probe.size
+    n = int(min(sample_u8.size, max(probe.size, budget_s / per_byte)))
+    n -= n % 4096
+    data = sample_u8[:n]
+    t0 = time.perf_counter()
+    et = F.encode(data, cores)
+    t1 = time.perf_counter()
+    back = F.decode(et[4:], cores)
+    t2 = time.perf_counter()
+    assert back == data.tobytes()
+    return {
+        "value": round(n / (t2 - t0) / 1e9, 4),
+        "unit": "GB/s",
+        "cores": cores,
+        "kind": "port-fast",
+        "sample": f"first {n >> 20} MiB of rank 0's text-1G stream, chunk-parallel lookup-table CPU variant, encode+decode "
+                  f"round trip (encode {n / (t1 - t0) / 1e6:.0f} MB/s, decode {n / (t2 - t1) / 1e6:.0f} MB/s), {cores} threads",
+    }
+
+
 def load_pmc_traffic(kernel):
     """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/pmc_latest.json), or None."""
     try:
@@ -78,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=int(os.environ.get("ET_BENCH_BYTES", 1 << 30)), help="text bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the chunk-parallel CPU baseline (0: min(cores, 16))")
     args = ap.parse_args()
 
     import torch
@@ -230,7 +261,9 @@ def main():
                             "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if v[0] else None} for k, v in kernels.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(text[: min(n, 768 << 20)].cpu().numpy())
+            host_text = text[: min(n, 1 << 30)].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(host_text[: 768 << 20])
+            out["cpu_baseline_parallel"] = cpu_baseline_parallel(host_text, args.cpu_threads)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     if world > 1 or force_group:

@@ -513,6 +513,33 @@ int64_t et_oracle_decode(const uint8_t *ct, size_t len, uint8_t *out, size_t cap
     return rc ? rc : (int64_t)written;
 }
 
+/* The dictionary of a stream as a code table (for et_cpu_fast.c's lookup decoder): the
+ * parse is parse_header above (decode.zig:34-141).  Returns 0 or -ET_ORACLE_FORMAT (also
+ * for a code longer than 32 bits, which the fast variant leaves to et_oracle_decode). */
+int64_t et_oracle_parse_dict(const uint8_t *ct, size_t len, et_oracle_dict *dict, uint64_t *body_start, uint32_t *body_length)
+{
+    code_table *tbl = (code_table *)calloc(1, sizeof *tbl);
+    if (!tbl) return -ET_ORACLE_NO_SPACE;
+    parsed_header ph;
+    int64_t rc = 0;
+    if (parse_header(ct, len, tbl, &ph, 64) || ph.oob || 5 + ph.global_pos > len) rc = -ET_ORACLE_FORMAT;
+    memset(dict, 0, sizeof *dict);
+    for (size_t k = 0; k < TBL_SLOTS && !rc; k++) {
+        const tbl_slot *s = &tbl->slot[k];
+        if (!s->used) continue;
+        for (unsigned l = 1; l <= 64; l++) {
+            if (!s->present[l - 1]) continue;
+            if (l > 32) { rc = -ET_ORACLE_FORMAT; break; }
+            dict->data[s->entry[l - 1]] = (uint32_t)s->key;
+            dict->length[s->entry[l - 1]] = (uint8_t)l;
+        }
+    }
+    *body_start = 5 + ph.global_pos;
+    *body_length = ph.body_length;
+    free(tbl);
+    return rc;
+}
+
 void et_oracle_format_file_size(float byte_count, char *buf, size_t cap) /* utils.zig:3-13 */
 {
     if (byte_count < 1024.0f) snprintf(buf, cap, "%g B", (double)byte_count);

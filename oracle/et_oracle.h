@@ -76,6 +76,23 @@ int64_t et_oracle_decode(const uint8_t *compressed, size_t len, uint8_t *out, si
 /* utils.zig:3-13 format_file_size (f32 argument).  Writes a NUL-terminated string. */
 void et_oracle_format_file_size(float byte_count, char *buf, size_t cap);
 
+/* decode.zig:34-141 as a code table: the stream's dictionary, where its body starts and the
+ * header's length field.  Returns 0 or -ET_ORACLE_FORMAT. */
+int64_t et_oracle_parse_dict(const uint8_t *compressed, size_t len, et_oracle_dict *dict,
+                             uint64_t *body_start, uint32_t *body_length);
+
+/* et_cpu_fast.c: the per-chunk pieces of a fast chunk-parallel CPU variant (bench.py's
+ * all-cores baseline).  Same outputs as the restatement above. */
+struct et_fast_tables;
+size_t et_fast_tables_size(void);
+int et_fast_build_tables(const et_oracle_dict *dict, struct et_fast_tables *t);
+uint64_t et_fast_pack(const et_oracle_dict *dict, const uint8_t *text, size_t n, uint8_t *out, uint64_t start_bit);
+uint64_t et_fast_walk(const struct et_fast_tables *t, const uint8_t *body, uint64_t total_bytes, uint64_t start_bit,
+                      uint64_t end_bit, uint64_t max_syms, uint8_t *out, uint64_t *exit_bit, uint32_t *marks,
+                      uint64_t mark_base, uint32_t n_marks);
+int et_fast_merge(const struct et_fast_tables *t, const uint8_t *body, uint64_t total_bytes, uint64_t p,
+                  const uint32_t *marks, uint64_t mark_base, uint32_t n_marks, uint64_t *extra, uint32_t *at);
+
 #ifdef __cplusplus
 }
 #endif

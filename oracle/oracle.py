@@ -23,7 +23,7 @@ class OracleError(Exception):
 
 def build():
     """Compile the oracle with gcc (no-op when the .so is newer than its sources)."""
-    srcs = [os.path.join(_HERE, f) for f in ("et_oracle.c", "et_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("et_oracle.c", "et_cpu_fast.c", "et_oracle.h")]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "libet_oracle.so"], stdout=subprocess.DEVNULL)

@@ -162,3 +162,20 @@ def test_format_file_size():
     assert O.format_file_size(477) == "477 B"
     assert O.format_file_size(112541) == "109.90 KB"
     assert O.format_file_size(5458199) == "5.21 MB"
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_fast_cpu_variant_equals_the_restatement(threads):
+    """oracle/et_cpu_fast.c (bench.py's all-cores CPU baseline): same .et bytes as the
+    restatement, and its chunk-parallel decode (walk, mark, merge at the true starts)
+    returns the input -- on text, a flat code (nothing to re-synchronise on: the merge
+    must still find the true boundaries), all 256 values (Q1), tiny and one-symbol inputs."""
+    from oracle import cpu_fast as F
+    from tests import corpus
+
+    cases = [corpus.text_like(1_200_000, 1), corpus.uniform(700_000, 2, 0, 256), corpus.uniform(600_000, 3, 1, 201),
+             corpus.text_like(100, 4), np.full(5000, 65, np.uint8), corpus.uniform(300_000, 5, 7, 9)]
+    for data in cases:
+        want = O.encode(data)
+        assert F.encode(data, threads) == want
+        assert F.decode(want[4:], threads) == O.decode(want[4:])

@@ -193,3 +193,102 @@ def test_decode_table_builders_under_asan_ubsan(tmp_path):
     subprocess.check_call(cmd)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+FAST_DRIVER = textwrap.dedent(r"""
+    #include "et_oracle.h"
+    #include <stdio.h>
+    #include <stdlib.h>
+    #include <string.h>
+    /* oracle/et_cpu_fast.c (bench.py's all-cores CPU baseline) against the restatement,
+       chunks run one after the other: pack at bit offsets, walk + mark + merge + write. */
+    static uint64_t rng = 0x2545F4914F6CDD1Dull;
+    static uint64_t next(void) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; }
+    #define MARKS 4096u
+    int main(void) {
+        for (int it = 0; it < 60; ++it) {
+            const size_t n = 1 + next() % 60000;
+            const int alphabet = 1 + next() % 256, skew = it % 3;
+            uint8_t *text = malloc(n), *et = malloc(n + 7200), *mine = calloc(n + 7200 + 16, 1), *back = malloc(n + 16);
+            for (size_t i = 0; i < n; ++i) {
+                uint64_t r = next();
+                text[i] = (uint8_t)(skew == 0 ? r % alphabet : skew == 1 ? (r % 7 ? r % 3 : r % alphabet) : __builtin_ctzll(r | (1ull << 40)) % alphabet);
+            }
+            const int64_t want = et_oracle_encode(text, n, et, n + 7200);
+            if (want < 0) { printf("oracle encode failed\n"); return 1; }
+            const int parts = 1 + it % 4;
+            uint64_t occ[256], hist[4][256], starts[5];
+            size_t cut[5];
+            for (int k = 0; k <= parts; ++k) cut[k] = n * k / parts;
+            memset(occ, 0, sizeof occ);
+            for (int k = 0; k < parts; ++k) {
+                et_oracle_histogram(text + cut[k], cut[k + 1] - cut[k], hist[k]);
+                for (int s = 0; s < 256; ++s) occ[s] += hist[k][s];
+            }
+            et_oracle_dict d;
+            if (et_oracle_build_dict(occ, &d, NULL, NULL)) { printf("dict failed\n"); return 1; }
+            const int64_t hb = et_oracle_write_header(&d, n, mine, n + 7200);
+            starts[0] = 8 * (uint64_t)hb;
+            for (int k = 0; k < parts; ++k) {
+                uint64_t b = 0;
+                for (int s = 0; s < 256; ++s) b += hist[k][s] * d.length[s];
+                starts[k + 1] = starts[k] + b;
+            }
+            for (int k = 0; k < parts; ++k)
+                if (et_fast_pack(&d, text + cut[k], cut[k + 1] - cut[k], mine, starts[k]) != starts[k + 1]) { printf("pack end mismatch\n"); return 1; }
+            if ((int64_t)((starts[parts] + 7) / 8) != want || memcmp(mine, et, (size_t)want)) { printf("encode mismatch (it %d)\n", it); return 1; }
+            /* decode */
+            et_oracle_dict pd; uint64_t body_start = 0; uint32_t body_len = 0;
+            if (et_oracle_parse_dict(et + 4, (size_t)want - 4, &pd, &body_start, &body_len)) {
+                int longest = 0;
+                for (int s = 0; s < 256; ++s) if (d.length[s] > longest) longest = d.length[s];
+                if (longest > 32 || n >= 256) { free(text); free(et); free(mine); free(back); continue; }  /* Q3 tables are not this variant's */
+                printf("parse_dict failed\n"); return 1;
+            }
+            struct et_fast_tables *t = malloc(et_fast_tables_size());
+            if (et_fast_build_tables(&pd, t)) { printf("tables failed\n"); return 1; }
+            const uint8_t *body = et + 4 + body_start;
+            const uint64_t body_bytes = (uint64_t)want - 4 - body_start;
+            uint64_t bcut[5], cnt[4], st[4], ex = 0, exit_bit = 0;
+            for (int k = 0; k <= parts; ++k) bcut[k] = 8 * (body_bytes * k / parts);
+            uint32_t *marks = malloc(MARKS * sizeof(uint32_t));
+            st[0] = 0;
+            cnt[0] = et_fast_walk(t, body, body_bytes, 0, bcut[1], ~0ull, NULL, &exit_bit, NULL, 0, 0);
+            for (int k = 1; k < parts; ++k) {
+                memset(marks, 0xff, MARKS * sizeof(uint32_t));
+                const uint64_t c = et_fast_walk(t, body, body_bytes, bcut[k], bcut[k + 1], ~0ull, NULL, &ex, marks, bcut[k], MARKS);
+                uint64_t extra = 0; uint32_t at = 0;
+                st[k] = exit_bit;
+                if (exit_bit >= bcut[k + 1]) cnt[k] = 0;
+                else if (et_fast_merge(t, body, body_bytes, exit_bit, marks, bcut[k], MARKS, &extra, &at)) { cnt[k] = extra + c - marks[at]; exit_bit = ex; }
+                else cnt[k] = et_fast_walk(t, body, body_bytes, exit_bit, bcut[k + 1], ~0ull, NULL, &exit_bit, NULL, 0, 0);
+            }
+            uint64_t off = 0;
+            for (int k = 0; k < parts; ++k) {
+                uint64_t lim = cnt[k];
+                if (off + lim > body_len) lim = body_len > off ? body_len - off : 0;
+                if (lim && et_fast_walk(t, body, body_bytes, st[k], ~0ull, lim, back + off, &ex, NULL, 0, 0) != lim) { printf("short write\n"); return 1; }
+                off += lim;
+            }
+            /* all 256 values present: the reference drops the most frequent symbol (Q1), the text does not come back */
+            int present = 0;
+            for (int s = 0; s < 256; ++s) present += occ[s] != 0;
+            if (present < 256 && (off != n || memcmp(back, text, n))) { printf("decode mismatch (it %d, parts %d, n %zu, got %llu)\n", it, parts, n, (unsigned long long)off); return 1; }
+            free(marks); free(t); free(text); free(et); free(mine); free(back);
+        }
+        printf("ok\n");
+        return 0;
+    }
+""")
+
+
+@pytest.mark.skipif(subprocess.run(["which", "gcc"], capture_output=True).returncode != 0, reason="gcc missing")
+def test_fast_cpu_variant_under_asan_ubsan(tmp_path):
+    src = tmp_path / "fast_driver.c"
+    src.write_text(FAST_DRIVER)
+    exe = tmp_path / "fast_driver"
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", f"-I{ROOT}/oracle",
+           str(src), f"{ROOT}/oracle/et_oracle.c", f"{ROOT}/oracle/et_cpu_fast.c", "-o", str(exe)]
+    subprocess.check_call(cmd)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
