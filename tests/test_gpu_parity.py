@@ -510,3 +510,38 @@ def test_decode_fuzz_dictionaries(ctx):
         accepted += 1
         assert len(out) <= declared
     assert accepted > 5  # some corrupted tables do remain decodable
+
+
+def test_two_contexts_on_two_threads(ctx):
+    """SURVEY 8b "Threading": the library is thread-safe per et_ctx handle and keeps no hidden
+    globals -- two host threads, each with its own context (own stream, workspaces, staging),
+    encode and decode different streams at the same time; every result equals the oracle's."""
+    import threading
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    jobs = [[corpus.text_like(n, 900 + i).tobytes() for i, n in enumerate(sizes)]
+            for sizes in ([3_000_001, 70_000, 1, 1_500_000], [2_000_003, 5, 900_000, 3_100_000])]
+    jobs[1].append(corpus.uniform(400_000, 7, 1, 201).tobytes())  # the exhaustive path, beside the other thread's text
+    want = [[O.encode(d) for d in js] for js in jobs]
+    errors = []
+
+    def work(k):
+        try:
+            mine = E.Context(0)
+            for rep in range(3):
+                for d, w in zip(jobs[k], want[k]):
+                    et = mine.encode(d)
+                    assert et == w, f"thread {k}: encode differs (n={len(d)})"
+                    assert mine.decode(et[4:]) == O.decode(w[4:]), f"thread {k}: decode differs (n={len(d)})"
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a worker thread hung"
+    assert not errors, errors
