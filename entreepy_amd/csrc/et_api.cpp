@@ -799,7 +799,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ET_HIP(hipEventSynchronize(ctx->ev_flags));  // not the stream: the write kernel keeps running while the caller moves on
         exhaustive = static_cast<uint64_t>(h_flags[1]) * 64 > n_blocks;
         more_sweeps = !exhaustive && h_flags[2] != 0;
-        if (exhaustive || more_sweeps) wrote = false;  // the speculative output is void
+        if (!et::dec_state_final(h_flags[1], h_flags[2], n_blocks)) wrote = false;  // the speculative launch declined by the same rule
     }
     if (exhaustive) {
         const uint32_t n_starts = cb->max_length;

@@ -36,6 +36,14 @@ constexpr uint32_t SYNC_CHUNK = ET_SYNC_CHUNK, WRITE_CHUNK = ET_WRITE_CHUNK;  //
 constexpr bool SYNC_TICKET = ET_SYNC_TICKET, WRITE_TICKET = ET_WRITE_TICKET;  // chunks by ticket counter vs one per workgroup
 constexpr uint32_t DEC_FIRST_SWEEP_TRIPS = 6;                   // local fixed-point trips before a block is declared non-synchronising
 constexpr uint32_t DEC_REPAIR_SWEEP_TRIPS = 8;                  // same cap for the two speculatively enqueued repair sweeps
+// ONE rule for "the sweeps left a final synchronisation state", applied by the host to its copy of
+// the flags and by a speculatively launched D3 to the flags themselves -- the two must agree, or the
+// host keeps output that the kernel declined to write: the verification passed, and no more blocks
+// gave up in the first sweep than the repair sweeps are meant for (beyond that the host goes the
+// exhaustive way).  Blocks that gave up AND were repaired by the second sweep are fine.
+__host__ __device__ inline bool dec_state_final(uint32_t gave_up, uint32_t verify_failed, uint32_t n_blocks) {
+    return verify_failed == 0 && static_cast<uint64_t>(gave_up) * 64 <= n_blocks;
+}
 constexpr uint32_t DEC_HAVE_START = 1, DEC_FRONT_OK = 2;       // k_dec_sync flags (ranges of a stream split over GPUs)
 constexpr uint32_t DEC_SPECIAL_SUPER = 8;                      // with DEC_SPECIAL_ONLY: the blocks of 16 KiB superblocks k_dec_sync_reg2 leaves out
 constexpr uint32_t DEC_SPECIAL_ONLY = 4;                       // k_dec_sync flag: first/last blocks only (k_dec_sync_reg has the rest)

@@ -1859,12 +1859,13 @@ __global__ __launch_bounds__(BLOCK) ET_WRITE_ATTR void k_dec_write_reg(const uin
                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ ticket,
                                                          const uint32_t *__restrict__ void_flags) {
     // A speculative launch (enqueued before the host has seen the sweeps' flags) does nothing
-    // when the synchronisation did not settle: void_flags[1] = blocks that gave up (their first
-    // subsequence carries the start marker 0xff, not a bit offset), void_flags[2] = the
-    // verification failed.  The host discards this launch's output in both cases and writes
-    // again once the state is final.  (Walking from the marker would send the packed walk state's
+    // when the synchronisation did not settle (dec_state_final, the host's own rule):
+    // void_flags[1] = blocks that gave up in the first sweep (their first subsequence carries the
+    // start marker 0xff until a repair sweep replaces it; one that is left fails the
+    // verification), void_flags[2] = the verification failed.  The host discards this launch's
+    // output in exactly these cases and writes again once the state is final.  (Walking from the marker would send the packed walk state's
     // address field through the LDS tables: a stream with long runs of one code hung this kernel.)
-    if (void_flags && (void_flags[1] | void_flags[2])) return;
+    if (void_flags && !dec_state_final(void_flags[1], void_flags[2], n_blocks)) return;
     // LDS: step table, its second-level tables | code lengths | scratch | stage
     uint32_t *wsteps = reinterpret_cast<uint32_t *>(dec_smem_raw);
     const uint32_t step_words = ta.words;
@@ -1937,7 +1938,7 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write(const uint32_t *__restrict_
                                                      const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ ticket, uint32_t special_only,
                                                      const uint32_t *__restrict__ void_flags) {
-    if (void_flags && (void_flags[1] | void_flags[2])) return;  // see k_dec_write_reg
+    if (void_flags && !dec_state_final(void_flags[1], void_flags[2], n_blocks)) return;  // see k_dec_write_reg
     const DecodeSmem m = carve_decode_smem<false>(tb);
     const int tid = threadIdx.x;
     stage_tables(m, tb);

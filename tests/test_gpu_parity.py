@@ -545,3 +545,25 @@ def test_two_contexts_on_two_threads(ctx):
         t.join(timeout=300)
     assert not any(t.is_alive() for t in threads), "a worker thread hung"
     assert not errors, errors
+
+
+@pytest.mark.parametrize("k,where,run", [(28, "end", 10_500), (28, "end", 7_000), (20, "end", 10_500), (28, "middle", 9_000), (12, "middle", 12_000)])
+def test_blocks_that_give_up_and_are_repaired(ctx, k, where, run):
+    """A SHORT run of one long code (here: 0xff under a unary-like code of up to k + 1 bits):
+    the blocks it covers hit the first sweep's trip cap, the repair sweep settles them and the
+    verification passes.  The speculative write and the host must judge that state by the same
+    rule -- a long soak found the kernel declining ("blocks gave up") while the host kept its
+    output ("verification passed"): all zeros, no error."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    rng = np.random.default_rng(608)
+    text = np.minimum(rng.geometric(0.5, size=2_500_000) - 1, k).astype(np.uint8)
+    good = bytearray(O.encode(text)[4:])
+    _, _, off = E.parse_header(bytes(good))
+    a = len(good) - run if where == "end" else off + (len(good) - off) // 2 + 1234
+    good[a : a + run] = b"\xff" * run
+    want = O.decode(bytes(good))
+    assert len(want) > 2_000_000
+    for _ in range(2):
+        assert ctx.decode(bytes(good)) == want
