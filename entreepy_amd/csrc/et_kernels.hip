@@ -758,7 +758,11 @@ __device__ __forceinline__ SubResult walk_subsequence(const DecodeSmem &m, const
     if (!off_stream) ET_WALK(end, true);
 #undef ET_WALK
 #undef ET_ADVANCE
-    res.exit_rel = off_stream ? 0u : pos - end;  // ran off the stream: nothing further begins here
+    // Ran off the stream (the code that begins at `pos` is cut by the stream's end): nothing further
+    // begins here OR in the few bits the stream may still have in the next subsequence -- the exit
+    // points at the stream's end, where the next walk stops at once.  (An exit of 0 let the next lane
+    // decode the cut code's tail as if a codeword began there; `lim - end` < 32, the cut code's length.)
+    res.exit_rel = off_stream ? (lim > end ? lim - end : 0u) : pos - end;
     res.count = count;
     return res;
 }

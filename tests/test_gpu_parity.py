@@ -567,3 +567,28 @@ def test_blocks_that_give_up_and_are_repaired(ctx, k, where, run):
     assert len(want) > 2_000_000
     for _ in range(2):
         assert ctx.decode(bytes(good)) == want
+
+
+def test_cut_code_across_the_last_subsequence_boundary(ctx):
+    """Truncated streams whose last 256-bit subsequence holds only 8 to 24 bits: when the
+    code cut by the stream's end BEGINS in the subsequence before, the lane that runs off the
+    stream must hand "the stream is over" to the last lane -- it once handed over bit 0, and the
+    last lane decoded the cut code's tail as one more symbol (found by tools/soak_fuzz.py).
+    A Zipf-like source (many 9..13-bit codes, so that cut codes are common); every such
+    truncation of a 3-block stream, checked against the oracle."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    rng = np.random.default_rng(2312)
+    p = 1.0 / (1.0 + np.arange(255))
+    text = (rng.choice(255, size=30_000, p=p / p.sum()) + 1).astype(np.uint8)
+    et = O.encode(text)[4:]
+    _, _, off = E.parse_header(et)
+    base = off - (off & 3)  # subsequences are counted from the aligned word the body starts in
+    checked = 0
+    for tail in (1, 2, 3):
+        for T in range(base + 64 + tail, len(et), 32):
+            data = et[:T]
+            assert ctx.decode(data) == O.decode(data), f"truncated to {T} bytes ({tail} in the last subsequence)"
+            checked += 1
+    assert checked > 1500
