@@ -56,6 +56,16 @@ def owned_words(starts, r):
     return lo, max(hi, lo)
 
 
+def cut_blocks(stream_bytes):
+    """8 KiB blocks a cold stream is cut over.  et_decode_range_sync wants >= 16 bytes of stream
+    after every range but the last (the run-out of a code that starts at the range's end), so a
+    last block shorter than that is not a block of its own: the range that ends the stream takes it."""
+    n_blocks = (stream_bytes + 8191) // 8192
+    if n_blocks > 1 and stream_bytes - (n_blocks - 1) * 8192 < 16:
+        n_blocks -= 1
+    return n_blocks
+
+
 class ShardedCodec:
     def __init__(self, ctx, group, device):
         self.ctx = ctx
@@ -159,9 +169,9 @@ class ShardedCodec:
         base_off = body_off - (ptr & 3)          # 4-byte aligned base of the body inside `compressed`
         first_bit = (ptr & 3) * 8
         stream = compressed[base_off:]
-        n_blocks = (stream.numel() + 8191) // 8192
+        n_blocks = cut_blocks(stream.numel())
         lo_b, hi_b = r * n_blocks // world, (r + 1) * n_blocks // world
-        begin, end = lo_b * 8192, min(hi_b * 8192, stream.numel())
+        begin, end = lo_b * 8192, (stream.numel() if hi_b == n_blocks else hi_b * 8192)
         active = hi_b > lo_b and cb.raw.n_coded > 0 and n_symbols > 0
         info = {"start_bit": 0, "exit_bit": 0, "n_symbols": 0}
         # Near-fixed-length codes do not self-synchronise: run-ins find nothing.  Every rank then

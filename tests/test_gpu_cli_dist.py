@@ -201,6 +201,60 @@ def test_cold_decode_virtual_ranks(ranks, res_files):
             c.close()
 
 
+@pytest.mark.parametrize("tail_bytes", [1, 5, 15, 16])
+def test_cold_decode_tiny_last_block(tail_bytes):
+    """A stream that ends a few bytes into its last 8 KiB block, cut over as many virtual ranks
+    as it has blocks: the block plan (sharded.cut_blocks) gives the tiny last block to the range
+    before it; the concatenated pieces equal the oracle's decode of the (truncated) stream."""
+    import torch
+
+    import entreepy_amd as E
+    from entreepy_amd.sharded import cut_blocks
+    from oracle import oracle as O
+
+    et = O.encode(corpus.text_like(120_000, 88))[4:]
+    cb, n_symbols, body_off = E.parse_header(et)
+    base = body_off - (body_off & 3)  # the tensor below is 4-byte aligned
+    et = et[: base + 5 * 8192 + tail_bytes]
+    comp = torch.from_numpy(np.frombuffer(et, dtype=np.uint8).copy()).cuda()
+    assert (comp.data_ptr() + body_off) & 3 == body_off & 3
+    first_bit = (body_off & 3) * 8
+    stream = comp[base:]
+    n_blocks = cut_blocks(stream.numel())
+    assert n_blocks == (5 if tail_bytes < 16 else 6)
+    ranks = n_blocks
+    ctxs, infos = [], []
+    for r in range(ranks):
+        lo, hi = r * n_blocks // ranks, (r + 1) * n_blocks // ranks
+        c = E.Context(0)
+        c.use_torch_stream()
+        begin, end = lo * 8192, (stream.numel() if hi == n_blocks else hi * 8192)
+        infos.append(c.decode_range_sync(cb, stream, begin, end, first_bit if lo == 0 else -1))
+        ctxs.append((c, begin, end))
+    for _ in range(ranks + 2):
+        prev, wrong = first_bit, []
+        for i, inf in enumerate(infos):
+            if inf["start_bit"] != prev:
+                wrong.append((i, prev))
+            prev = inf["exit_bit"]
+        if not wrong:
+            break
+        for i, w in wrong:
+            infos[i] = ctxs[i][0].decode_range_sync(cb, stream, ctxs[i][1], ctxs[i][2], w)
+    else:
+        raise AssertionError("did not settle")
+    out, first = [], 0
+    for (c, _, _), inf in zip(ctxs, infos):
+        take = max(0, min(inf["n_symbols"], n_symbols - first))
+        buf = torch.empty(inf["n_symbols"] + 64, dtype=torch.uint8, device="cuda")
+        m = c.decode_range_write(take, buf)
+        torch.cuda.synchronize()
+        out.append(buf[:m].cpu().numpy())
+        first += inf["n_symbols"]
+        c.close()
+    assert np.concatenate(out).tobytes() == O.decode(et)
+
+
 @pytest.mark.parametrize("ranks", [2, 5])
 def test_cold_decode_exhaustive_virtual_ranks(ranks):
     """et_decode_range_maps / _resolve: a stream of near-fixed-length codes (uniform alphabet:

@@ -175,3 +175,22 @@ def test_check_magic():
     assert N.lib().et_check_magic(bytes.fromhex("e7c0de02"), ctypes.byref(why)) == N.ET_ERR_FORMAT and b"version" in why.value
     assert N.lib().et_check_magic(b"PK\x03\x04", ctypes.byref(why)) == N.ET_ERR_FORMAT and b"magic" in why.value
     assert N.lib().et_check_magic(bytes.fromhex("e7c0de01"), None) == N.ET_OK
+
+
+def test_cold_decode_block_plan_keeps_16_bytes_behind_every_inner_range():
+    """sharded.cut_blocks: a last block shorter than 16 bytes is not cut off on its own (the range
+    before it would have no run-out room, et_decode_range_sync refuses that)."""
+    from entreepy_amd.sharded import cut_blocks
+
+    assert cut_blocks(8192 * 5) == 5
+    assert cut_blocks(8192 * 5 + 15) == 5
+    assert cut_blocks(8192 * 5 + 16) == 6
+    assert cut_blocks(7) == 1 and cut_blocks(8192) == 1 and cut_blocks(8192 + 1) == 1
+    for nbytes in (8192 * 8 + 5, 8192 * 3 + 16, 100, 8192 * 2):
+        n_blocks = cut_blocks(nbytes)
+        for world in (1, 2, 3, 8, 16):
+            for r in range(world):
+                lo, hi = r * n_blocks // world, (r + 1) * n_blocks // world
+                if hi > lo:
+                    end = nbytes if hi == n_blocks else hi * 8192
+                    assert end == nbytes or nbytes - end >= 16
