@@ -47,9 +47,39 @@ def main():
             n = text.size
         want = O.encode(text)
         ctx.set_tile_rounds(int(rng.choice([0, 0, 1, 2, 4, 8, 16])))
-        mode = int(rng.integers(0, 2))
+        mode = int(rng.integers(0, 3))
+        if mode == 2 and int(O.build_dict(O.histogram(text))[1].max()) > 32:
+            mode = 0  # (the staged calls take code tables of up to 32 bits)
         if mode == 0:
             got = ctx.encode(text)
+        elif mode == 2:  # virtual shards: uneven (also empty / tiny) pieces, one table, bit-offset concat
+            shards = int(rng.integers(2, 9))
+            bounds = np.sort(np.concatenate([[0, n], rng.integers(0, n + 1, size=shards - 1)])).astype(np.int64)
+            t = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+            hists = []
+            for r in range(shards):
+                h = torch.zeros(256, dtype=torch.int64, device="cuda")
+                if bounds[r + 1] > bounds[r]:
+                    ctx.histogram_device(t[bounds[r] : bounds[r + 1]], h)
+                hists.append(h.cpu().numpy().astype(np.uint64))
+            cb = E.Codebook.from_histogram(np.sum(hists, axis=0).astype(np.uint64))
+            header = cb.header(n)
+            img = np.zeros(len(want) + 16, dtype=np.uint8)
+            img[: len(header)] = np.frombuffer(header, dtype=np.uint8)
+            bit = len(header) * 8
+            for r in range(shards):
+                view = t[bounds[r] : bounds[r + 1]]
+                if view.numel() == 0:
+                    continue
+                ctx.histogram_device(view, torch.zeros(256, dtype=torch.int64, device="cuda"))  # the staged protocol: K1 first
+                out = torch.zeros(view.numel() * 4 + 64, dtype=torch.uint8, device="cuda")
+                end = ctx.encode_body_device(cb, view, out, bit % 32)
+                torch.cuda.synchronize()
+                piece = out[: (end + 7) // 8].cpu().numpy()
+                base_byte = (bit // 32) * 4
+                img[base_byte : base_byte + piece.size] |= piece
+                bit += end - bit % 32
+            got = img[: (bit + 7) // 8].tobytes()
         else:
             lo = int(rng.integers(0, 16))
             buf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
