@@ -24,7 +24,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBPS = 6290.0  # same guide: what a float4 copy reaches (report against both, headline against spec)
 
 
 def cpu_baseline(sample_u8, budget_s=14.0):
@@ -253,6 +254,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
                 "traffic": load_pmc_traffic(dominant.split("<")[0]),
                 "ms_per_launch": round(d_ms, 4),
                 "algorithmic_bytes_per_launch": d_bytes,
