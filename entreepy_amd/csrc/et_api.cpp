@@ -37,7 +37,7 @@ constexpr size_t SUB_TABLE_ONLY = (static_cast<size_t>(et::DEC_SUB_TABLES_MAX) <
 constexpr size_t SUB_TABLE_BYTES = SUB_TABLE_ONLY + 256;
 constexpr size_t DEC_STEPS_OFFSET = (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) * 2 + 1024 * sizeof(uint32_t) + 2 * SUB_TABLE_BYTES;  // multiple of 64
 constexpr size_t DEC_TABLES_BYTES = DEC_STEPS_OFFSET + (sizeof(uint32_t) << et::DEC_STEP_BITS_MAX) + (sizeof(uint32_t) << et::DEC_LUT_BITS_MAX) +
-                                    2 * (et::DEC_STEP_SUB_WORDS + 4) * sizeof(uint32_t) + 2 * sizeof(et::DecodeTables) + 64;
+                                    2 * (et::DEC_STEP_SUB_WORDS + 4) * sizeof(uint32_t) + 2 * sizeof(et::DecodeTables) + sizeof(et::TablePlan) + 64;
 //  // the per-symbol code lengths ride behind the tables  // + slack for 16-byte rounded copies
 
 }  // namespace
@@ -66,7 +66,11 @@ struct et_ctx {
     uint64_t *h_hist = nullptr;     // 256
     uint32_t *h_enc = nullptr;      // 768: {code,len} x 256, then len x 256
     uint8_t *h_header = nullptr;    // HEADER_STAGE
-    uint32_t *h_lut = nullptr;      // 1 << DEC_LUT_BITS_MAX
+    uint32_t *h_lut = nullptr;      // the decode tables being built (one of h_lut_buf)
+    uint32_t *h_lut_buf[2] = {};    // DEC_TABLES_BYTES each, used in turn: the host fills one while the other's upload may still be queued
+    hipEvent_t ev_lut[2] = {};      // recorded behind the upload from h_lut_buf[i]
+    bool lut_queued[2] = {};
+    int lut_turn = 0;
     uint64_t *h_scalar = nullptr;   // 16: [1] a total, [2..3] flags (range decode), [4..11] the body decode's copy of flag[0..15]
 
     // link between et_histogram_device and et_encode_body_device
@@ -307,7 +311,11 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hist), 256 * sizeof(uint64_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 768 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut), DEC_TABLES_BYTES) == hipSuccess;
+    for (int i = 0; i < 2; ++i) {
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut_buf[i]), DEC_TABLES_BYTES) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ctx->ev_lut[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ctx->h_lut = ctx->h_lut_buf[0];
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 16 * sizeof(uint64_t)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->ev_flags, hipEventDisableTiming) == hipSuccess;
@@ -330,7 +338,9 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     delete ctx->io;
-    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_header, ctx->h_lut, ctx->h_scalar};
+    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_header, ctx->h_lut_buf[0], ctx->h_lut_buf[1], ctx->h_scalar};
+    for (auto &e : ctx->ev_lut)
+        if (e) (void)hipEventDestroy(e);
     for (void *p : pinned)
         if (p) (void)hipHostFree(p);
     for (auto &e : ctx->ev)
@@ -654,32 +664,51 @@ using et::build_decode_tables;
 using et::build_step_table;
 using et::build_write_step_table;
 
-int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *tb_out, et::DecodeTables *tb_write_out) {
+// zero16 / zeroed (optional): 16 device words the table-building kernel clears on its way, and
+// whether it did (the host-built variant has no kernel: the caller clears them itself).
+int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *tb_out, et::DecodeTables *tb_write_out, uint32_t *zero16 = nullptr,
+                          bool *zeroed = nullptr) {
+    if (zeroed) *zeroed = false;
     // one pinned block, one device block, one upload: [first-level x 2 | long lists | second-level (+ lengths) x 2]
     ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
-    ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned tables may still feed an earlier call
+    // Two pinned blocks used in turn: the upload from the one filled two calls ago is long done
+    // (its event says so), so the host builds these tables while the stream is still busy with
+    // whatever precedes this decode -- no stream-wide wait here.
+    const int turn = ctx->lut_turn ^= 1;
+    if (ctx->lut_queued[turn]) ET_HIP(hipEventSynchronize(ctx->ev_lut[turn]));
+    ctx->h_lut = ctx->h_lut_buf[turn];
+    static const bool on_host = [] { const char *e = std::getenv("ET_DEC_TABLES_HOST"); return e && e[0] == '1'; }();  // A/B switch, and the reference the device's tables are tested against
     HostDecodeTables ht, hw;
     uint32_t *h_lut_w = ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX);
     uint32_t *h_long = ctx->h_lut + (2u << et::DEC_LUT_BITS_MAX), *h_long_w = h_long + 512;
     uint16_t *h_sub = reinterpret_cast<uint16_t *>(h_long + 1024);
     uint16_t *h_sub_w = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(h_sub) + SUB_TABLE_BYTES);
-    (void)h_long;
-    (void)h_sub;
-    build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
-    ht = hw;
-    std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
     uint32_t *h_steps = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->h_lut) + DEC_STEPS_OFFSET);
-    uint32_t step_sub_bits = 0, n_step_sub = 0;
-    const uint32_t step_bits = build_step_table(cb, ctx->step_bits, h_steps, &step_sub_bits, &n_step_sub);
+    uint32_t step_bits = 0, step_sub_bits = 0, n_step_sub = 0, wstep_bits = 0, wstep_sub_bits = 0, n_wstep_sub = 0;
+    et::TablePlan plan;
+    if (on_host) {
+        build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, h_lut_w, h_long_w, h_sub_w, &hw);
+        std::memcpy(reinterpret_cast<uint8_t *>(h_sub_w) + SUB_TABLE_ONLY, cb->length, 256);
+        step_bits = build_step_table(cb, ctx->step_bits, h_steps, &step_sub_bits, &n_step_sub);
+    } else {  // the host only decides (widths, second-level tables, long-list order); k_build_dec_tables fills
+        et::plan_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, ctx->step_bits, ctx->lut_bits_write, &plan);
+        hw = HostDecodeTables{plan.lut_bits, plan.n_long, plan.sub_bits, plan.n_sub};
+        step_bits = plan.step_bits;
+        step_sub_bits = plan.step_sub_bits;
+        n_step_sub = plan.n_step_sub;
+        wstep_bits = plan.wstep_bits;
+        wstep_sub_bits = plan.wstep_sub_bits;
+        n_wstep_sub = plan.n_wstep_sub;
+    }
+    ht = hw;
     const size_t step_bytes = (((static_cast<size_t>(1) << step_bits) + (static_cast<size_t>(n_step_sub) << step_sub_bits) + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t);
     uint32_t *h_wsteps = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(h_steps) + step_bytes);  // right behind, one upload
-    uint32_t wstep_sub_bits = 0, n_wstep_sub = 0;
-    const uint32_t wstep_bits = build_write_step_table(cb, ctx->lut_bits_write, h_wsteps, &wstep_sub_bits, &n_wstep_sub);
+    if (on_host) wstep_bits = build_write_step_table(cb, ctx->lut_bits_write, h_wsteps, &wstep_sub_bits, &n_wstep_sub);
     const size_t wstep_bytes = (((static_cast<size_t>(1) << wstep_bits) + (static_cast<size_t>(n_wstep_sub) << wstep_sub_bits) + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t);
-    const uint32_t *d_lut = static_cast<const uint32_t *>(ctx->lut.p);
-    const uint32_t *d_long = d_lut + (2u << et::DEC_LUT_BITS_MAX);
-    const uint8_t *subt = reinterpret_cast<const uint8_t *>(d_long + 1024);
+    uint32_t *d_lut = static_cast<uint32_t *>(ctx->lut.p);
+    uint32_t *d_long = d_lut + (2u << et::DEC_LUT_BITS_MAX);
+    uint8_t *subt = reinterpret_cast<uint8_t *>(d_long + 1024);
     *tb_out = et::DecodeTables{d_lut + (1u << et::DEC_LUT_BITS_MAX), d_long + 512, reinterpret_cast<const uint16_t *>(subt + SUB_TABLE_BYTES),
                                subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY, ht.lut_bits, ht.n_long, ht.sub_bits,
                                ht.n_sub, reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET), step_bits,
@@ -689,7 +718,7 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
                                      hw.lut_bits, hw.n_long, hw.sub_bits, hw.n_sub,
                                      reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_lut) + DEC_STEPS_OFFSET + step_bytes), wstep_bits,
                                      wstep_sub_bits, n_wstep_sub, nullptr};
-    // device copies of the two structs ride behind the tables (slow path of the step walks)
+    // device copies of the two structs ride behind the tables (slow path of the step walks), the plan behind them
     const size_t structs_at = DEC_STEPS_OFFSET + step_bytes + wstep_bytes;
     const et::DecodeTables *d_structs = reinterpret_cast<const et::DecodeTables *>(reinterpret_cast<const uint8_t *>(d_lut) + structs_at);
     tb_out->dev_copy = d_structs;
@@ -697,11 +726,57 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     et::DecodeTables *h_structs = reinterpret_cast<et::DecodeTables *>(reinterpret_cast<uint8_t *>(ctx->h_lut) + structs_at);
     h_structs[0] = *tb_out;
     h_structs[1] = *tb_write_out;
-    ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, structs_at + 2 * sizeof(et::DecodeTables), hipMemcpyHostToDevice, ctx->stream));
+    if (on_host) {
+        ET_HIP(hipMemcpyAsync(ctx->lut.p, ctx->h_lut, structs_at + 2 * sizeof(et::DecodeTables), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        std::memcpy(h_structs + 2, &plan, sizeof plan);
+        uint8_t *d_block = reinterpret_cast<uint8_t *>(d_lut);
+        ET_HIP(hipMemcpyAsync(d_block + structs_at, h_structs, 2 * sizeof(et::DecodeTables) + sizeof plan, hipMemcpyHostToDevice, ctx->stream));
+        et::launch_build_dec_tables(ctx->stream, reinterpret_cast<const et::TablePlan *>(d_block + structs_at + 2 * sizeof(et::DecodeTables)),
+                                    d_lut + (1u << et::DEC_LUT_BITS_MAX), d_long + 512, reinterpret_cast<uint16_t *>(subt + SUB_TABLE_BYTES),
+                                    subt + SUB_TABLE_BYTES + SUB_TABLE_ONLY, reinterpret_cast<uint32_t *>(d_block + DEC_STEPS_OFFSET),
+                                    reinterpret_cast<uint32_t *>(d_block + DEC_STEPS_OFFSET + step_bytes), zero16);
+        ET_HIP(hipGetLastError());
+        if (zeroed) *zeroed = zero16 != nullptr;
+    }
+    ET_HIP(hipEventRecord(ctx->ev_lut[turn], ctx->stream));
+    ctx->lut_queued[turn] = true;
     return ET_OK;
 }
 
 }  // namespace
+
+extern "C" int et_selftest_decode_tables(et_ctx *ctx, const et_codebook *cb, int *where) {
+    if (!ctx || !cb || !where) return ET_ERR_ARG;
+    *where = 0;
+    if (cb->max_length > 32 || cb->n_coded == 0) return fail(ctx, ET_ERR_UNSUPPORTED, "no decode tables for this code table");
+    DeviceGuard guard(ctx->device);
+    et::DecodeTables tb, tbw;
+    ET_TRY(prepare_decode_tables(ctx, cb, &tb, &tbw));  // the device's (unless ET_DEC_TABLES_HOST=1: then this compares the host's with themselves)
+    std::vector<uint8_t> dev(DEC_TABLES_BYTES);
+    ET_HIP(hipMemcpyAsync(dev.data(), ctx->lut.p, DEC_TABLES_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> lut(1u << et::DEC_LUT_BITS_MAX), longc(512), steps((1u << et::DEC_STEP_BITS_MAX) + et::DEC_STEP_SUB_WORDS + 8),
+        wsteps((1u << et::DEC_LUT_BITS_MAX) + et::DEC_STEP_SUB_WORDS + 8);
+    std::vector<uint16_t> sub(SUB_TABLE_ONLY / 2);
+    HostDecodeTables hw;
+    build_decode_tables(cb, ctx->lut_bits_write, et::DEC_WRITE_SYMS, lut.data(), longc.data(), sub.data(), &hw);
+    uint32_t ssb = 0, nss = 0, wsb = 0, nws = 0;
+    const uint32_t sbits = build_step_table(cb, ctx->step_bits, steps.data(), &ssb, &nss);
+    const uint32_t wbits = build_write_step_table(cb, ctx->lut_bits_write, wsteps.data(), &wsb, &nws);
+    auto at = [&](const void *dptr) { return dev.data() + (static_cast<const uint8_t *>(dptr) - static_cast<const uint8_t *>(ctx->lut.p)); };
+    const bool meta_ok = hw.lut_bits == tbw.lut_bits && hw.n_long == tbw.n_long && hw.sub_bits == tbw.sub_bits && hw.n_sub == tbw.n_sub &&
+                         sbits == tb.step_bits && ssb == tb.step_sub_bits && nss == tb.n_step_sub && wbits == tbw.step_bits &&
+                         wsb == tbw.step_sub_bits && nws == tbw.n_step_sub;
+    if (!meta_ok) *where = 7;
+    else if (std::memcmp(at(tbw.lut), lut.data(), sizeof(uint32_t) << hw.lut_bits)) *where = 1;
+    else if (std::memcmp(at(tbw.longc), longc.data(), 2 * sizeof(uint32_t) * hw.n_long)) *where = 2;
+    else if (std::memcmp(at(tbw.sub), sub.data(), (sizeof(uint16_t) * hw.n_sub) << hw.sub_bits)) *where = 3;
+    else if (std::memcmp(at(tbw.sym_len), cb->length, 256)) *where = 4;
+    else if (std::memcmp(at(tb.steps), steps.data(), sizeof(uint32_t) * ((1u << sbits) + (nss << ssb)))) *where = 5;
+    else if (std::memcmp(at(tbw.steps), wsteps.data(), sizeof(uint32_t) * ((1u << wbits) + (nws << wsb)))) *where = 6;
+    return *where ? fail(ctx, ET_ERR_FORMAT, "device-built decode tables differ from the host builders'") : ET_OK;
+}
 
 extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body, size_t body_bytes, uint32_t start_bit,
                                      uint64_t n_symbols, void *d_out, size_t cap, size_t *out_len) {
@@ -732,7 +807,9 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     ctx->range.valid = false;  // shares the workspaces
     const double t0 = now_ms();
     et::DecodeTables tb, tb_write;
-    ET_TRY(prepare_decode_tables(ctx, cb, &tb, &tb_write));
+    ET_TRY(ensure(ctx, ctx->flag, 64));
+    bool flags_zeroed = false;
+    ET_TRY(prepare_decode_tables(ctx, cb, &tb, &tb_write, static_cast<uint32_t *>(ctx->flag.p), &flags_zeroed));
     const double t1 = now_ms();
     record(ctx, EV_DEC + 0);
 
@@ -780,7 +857,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
     bool more_sweeps = false;
     if (!exhaustive) {
-        ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
+        if (!flags_zeroed) ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
         write_ticket_zero = true;
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
                             et::DEC_HAVE_START, nullptr, nullptr, side, true);

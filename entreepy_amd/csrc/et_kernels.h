@@ -99,6 +99,12 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
                            const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps,
                            uint8_t *grp_maps, uint8_t *blk_in, uint8_t *grp_in, uint32_t *sub_state, uint32_t *blk_exit,
                            uint32_t *blk_count);
+// Fill the decode tables on the device from the host's plan (d_plan in device memory).  Layout of
+// the outputs as the host builders': lut[1 << lut_bits], longc[2 * n_long], sub[n_sub << sub_bits],
+// sym_len[256], steps[(1 << step_bits) + second level], wsteps[(1 << wstep_bits) + second level].
+// zero16 (optional): 16 words the kernel also clears (the decode's flags).
+void launch_build_dec_tables(hipStream_t stream, const TablePlan *d_plan, uint32_t *lut, uint32_t *longc, uint16_t *sub, uint8_t *sym_len,
+                             uint32_t *steps, uint32_t *wsteps, uint32_t *zero16 = nullptr);
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
                      unsigned long long *blk_off, unsigned long long *total_copy = nullptr, const uint32_t *verify_state = nullptr,
                      const uint32_t *verify_exit = nullptr, uint32_t *verify_flag = nullptr, uint32_t verify_first = 0xffffffffu);

@@ -2086,6 +2086,139 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
         hipLaunchKernelGGL(k_encode_tiles<8192>, dim3(tile_grid(k_encode_tiles<8192>, n_tiles)), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
 }
 
+// ---------------------------------------------------------------------------------
+// The decode tables, filled on the device from the host's plan (et_tables.h TablePlan): one
+// workgroup of 1024.  The host builders (et_tables.cpp) cost ~48 us per decode call, which a
+// device-resident .et pays in full with the GPU idle (the header has to come to the host first);
+// this kernel is ~5 us.  Entry for entry what build_decode_tables / build_step_table /
+// build_write_step_table produce -- tests/test_gpu_parity.py compares the two.
+//   phase 1  a wavefront per symbol: its span of the "which code prefixes this index" arrays
+//            (LDS), or -- a code longer than the index -- its long-list entry, the first-level
+//            escape of its prefix and its span of the second-level table
+//   phase 2  a thread per first-level entry: the greedy walk over whole codes inside the index
+// ---------------------------------------------------------------------------------
+constexpr uint32_t BUILD_THREADS = 1024;
+__global__ __launch_bounds__(BUILD_THREADS) void k_build_dec_tables(const TablePlan *plan, uint32_t *__restrict__ lut,
+                                                                   uint32_t *__restrict__ longc, uint16_t *__restrict__ sub,
+                                                                   uint8_t *__restrict__ sym_len, uint32_t *__restrict__ steps,
+                                                                   uint32_t *__restrict__ wsteps, uint32_t *__restrict__ zero16) {
+    __shared__ TablePlan plan_lds;  // (read per symbol below: from global memory each of those reads is a microsecond)
+    static_assert(sizeof(TablePlan) % 4 == 0, "copied by words");
+    for (uint32_t i = threadIdx.x; i < sizeof(TablePlan) / 4; i += BUILD_THREADS)
+        reinterpret_cast<uint32_t *>(&plan_lds)[i] = reinterpret_cast<const uint32_t *>(plan)[i];
+    if (zero16 && threadIdx.x < 16) zero16[threadIdx.x] = 0;  // the decode's flag words (saves the caller a memset launch)
+    __syncthreads();
+    plan = &plan_lds;
+    __shared__ uint16_t single[1u << DEC_LUT_BITS_MAX];      // (len << 8) | sym of the code that prefixes a lut_bits index
+    __shared__ uint8_t first_step[1u << DEC_STEP_BITS_MAX];  // its length, for a step_bits index
+    __shared__ uint8_t of_lut[1u << DEC_LUT_BITS_MAX], of_step[1u << DEC_STEP_BITS_MAX], of_w[1u << DEC_LUT_BITS_MAX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t k = plan->lut_bits, ks = plan->step_bits, kw = plan->wstep_bits;  // kw == k (one index width for both write-side tables)
+    const uint32_t sub_bits = plan->sub_bits, ssub_bits = plan->step_sub_bits, wsub_bits = plan->wstep_sub_bits;
+    const uint32_t n = 1u << k, ns = 1u << ks, nw = 1u << kw;
+    uint32_t *ssub = steps + ns, *wsub = wsteps + nw;
+    for (uint32_t i = tid; i < n; i += BUILD_THREADS) {
+        single[i] = 0;
+        of_lut[i] = 0;
+        of_w[i] = 0;
+    }
+    for (uint32_t i = tid; i < ns; i += BUILD_THREADS) {
+        first_step[i] = 0;
+        of_step[i] = 0;
+    }
+    for (uint32_t i = tid; i < (plan->n_sub << sub_bits); i += BUILD_THREADS) sub[i] = 0;
+    for (uint32_t i = tid; i < (plan->n_step_sub << ssub_bits); i += BUILD_THREADS) ssub[i] = 0;
+    for (uint32_t i = tid; i < (plan->n_wstep_sub << wsub_bits); i += BUILD_THREADS) wsub[i] = 0;
+    if (tid < 256) sym_len[tid] = plan->length[tid];
+    __syncthreads();
+    for (uint32_t s = wave; s < 256; s += BUILD_THREADS / 64) {
+        const uint32_t len = plan->length[s];
+        if (!len) continue;
+        const uint32_t code = plan->data[s], meta = (len << 8) | s;
+        if (len <= k) {  // (kw == k: the write-step table shares `single`)
+            const uint32_t lo = code << (k - len), span = 1u << (k - len);
+            for (uint32_t i = lane; i < span; i += 64) single[lo + i] = static_cast<uint16_t>(meta);
+        } else {
+            const uint32_t prefix = code >> (len - k), rest_bits = len - k;
+            if (lane == 0) {
+                longc[2 * plan->long_idx[s]] = code << (32 - len);
+                longc[2 * plan->long_idx[s] + 1] = meta;
+            }
+            const uint32_t t_lut = plan->lut_sub[s], t_w = plan->wstep_sub[s];
+            if (t_lut) {
+                if (lane == 0) of_lut[prefix] = static_cast<uint8_t>(t_lut);
+                if (rest_bits <= sub_bits) {
+                    const uint32_t lo = ((code & ((1u << rest_bits) - 1u)) << (sub_bits - rest_bits)) + ((t_lut - 1) << sub_bits);
+                    for (uint32_t i = lane; i < (1u << (sub_bits - rest_bits)); i += 64) sub[lo + i] = static_cast<uint16_t>(meta);
+                }
+            }
+            if (t_w) {
+                if (lane == 0) of_w[prefix] = static_cast<uint8_t>(t_w);
+                if (rest_bits <= wsub_bits) {
+                    const uint32_t lo = ((code & ((1u << rest_bits) - 1u)) << (wsub_bits - rest_bits)) + ((t_w - 1) << wsub_bits);
+                    for (uint32_t i = lane; i < (1u << (wsub_bits - rest_bits)); i += 64) wsub[lo + i] = (s << 16) | ((1u << 10) - len);
+                }
+            }
+        }
+        if (len <= ks) {
+            const uint32_t lo = code << (ks - len), span = 1u << (ks - len);
+            for (uint32_t i = lane; i < span; i += 64) first_step[lo + i] = static_cast<uint8_t>(len);
+        } else {
+            const uint32_t prefix = code >> (len - ks), rest_bits = len - ks, t_s = plan->step_sub[s];
+            if (t_s) {
+                if (lane == 0) of_step[prefix] = static_cast<uint8_t>(t_s);
+                if (rest_bits <= ssub_bits) {
+                    const uint32_t lo = ((code & ((1u << rest_bits) - 1u)) << (ssub_bits - rest_bits)) + ((t_s - 1) << ssub_bits);
+                    for (uint32_t i = lane; i < (1u << (ssub_bits - rest_bits)); i += 64) ssub[lo + i] = (1u << 16) - len;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t max_syms = plan->max_syms;
+    for (uint32_t v = tid; v < n; v += BUILD_THREADS) {
+        {  // older format: up to max_syms whole codes
+            uint32_t entry = 0, used = 0, cnt = 0;
+            while (cnt < max_syms) {
+                const uint32_t e = single[(v << used) & (n - 1)], len = e >> 8;
+                if (!len || used + len > k) break;
+                entry |= (e & 0xffu) << (8 * cnt);
+                used += len;
+                ++cnt;
+            }
+            if (cnt) entry |= (used << LUT_LEN_SHIFT) | (cnt << LUT_N_SHIFT);
+            else if (of_lut[v]) entry = static_cast<uint32_t>(of_lut[v] - 1) | (1u << LUT_SUB_SHIFT);
+            lut[v] = entry;
+        }
+        {  // write-step table: two symbols and what the step adds to the walk state
+            uint32_t used = 0, cnt = 0, syms = 0;
+            while (cnt < 2) {
+                const uint32_t f = single[(v << used) & (n - 1)], len = f >> 8;
+                if (!len || used + len > k) break;
+                syms |= (f & 0xffu) << (16 + 8 * cnt);
+                used += len;
+                ++cnt;
+            }
+            wsteps[v] = cnt ? syms | (((cnt << 10) - used) & 0xffffu) : (static_cast<uint32_t>(of_w[v]) << 24) | WSTEP_ESCAPE;
+        }
+    }
+    for (uint32_t v = tid; v < ns; v += BUILD_THREADS) {
+        uint32_t used = 0, cnt = 0;
+        for (;;) {
+            const uint32_t len = first_step[(v << used) & (ns - 1)];
+            if (!len || used + len > ks) break;
+            used += len;
+            ++cnt;
+        }
+        steps[v] = cnt ? (static_cast<uint32_t>(first_step[v]) << 28) + (cnt << 16) - used : STEP_ESCAPE + (static_cast<uint32_t>(of_step[v]) << 28);
+    }
+}
+
+void launch_build_dec_tables(hipStream_t stream, const TablePlan *d_plan, uint32_t *lut, uint32_t *longc, uint16_t *sub, uint8_t *sym_len,
+                             uint32_t *steps, uint32_t *wsteps, uint32_t *zero16) {
+    hipLaunchKernelGGL(k_build_dec_tables, dim3(1), dim3(BUILD_THREADS), 0, stream, d_plan, lut, longc, sub, sym_len, steps, wsteps, zero16);
+}
+
 // Grid of a chunked decode kernel: one workgroup per chunk, or -- ticketed -- as many
 // workgroups as the occupancy API reports resident (an over-estimate is harmless).
 template <typename K>

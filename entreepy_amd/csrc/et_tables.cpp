@@ -154,4 +154,54 @@ uint32_t build_write_step_table(const et_codebook *cb, uint32_t bits_max, uint32
     return k;
 }
 
+// The decisions of the three builders above without the fills (same loops, same order).
+void plan_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t max_syms, uint32_t step_bits_max, uint32_t wstep_bits_max, TablePlan *p) {
+    std::memcpy(p->data, cb->data, sizeof p->data);
+    std::memcpy(p->length, cb->length, sizeof p->length);
+    std::memset(p->lut_sub, 0, 256);
+    std::memset(p->step_sub, 0, 256);
+    std::memset(p->wstep_sub, 0, 256);
+    std::memset(p->long_idx, 0, 256);
+    const uint32_t longest = cb->max_length ? cb->max_length : 1;
+    auto width = [&](uint32_t most) { return cb->max_length < most ? longest : most; };
+    auto sub_width = [&](uint32_t k) { return cb->max_length > k ? (cb->max_length - k < DEC_SUB_BITS_MAX ? cb->max_length - k : DEC_SUB_BITS_MAX) : 0u; };
+    p->lut_bits = width(lut_bits_max);
+    p->step_bits = width(step_bits_max);
+    p->wstep_bits = width(wstep_bits_max);
+    p->sub_bits = sub_width(p->lut_bits);
+    p->step_sub_bits = sub_width(p->step_bits);
+    p->wstep_sub_bits = sub_width(p->wstep_bits);
+    p->max_syms = max_syms;
+    p->pad_ = 0;
+    uint8_t of_lut[1u << DEC_LUT_BITS_MAX], of_step[1u << DEC_STEP_BITS_MAX], of_w[1u << DEC_LUT_BITS_MAX];  // (stack: this runs once per decode call)
+    std::memset(of_lut, 0, static_cast<size_t>(1) << p->lut_bits);
+    std::memset(of_step, 0, static_cast<size_t>(1) << p->step_bits);
+    std::memset(of_w, 0, static_cast<size_t>(1) << p->wstep_bits);
+    uint32_t nl = 0, n_sub = 0, n_step = 0, n_w = 0;
+    for (int s = 0; s < 256; ++s) {
+        const uint32_t len = cb->length[s];
+        if (!len) continue;
+        if (len > p->lut_bits) {
+            p->long_idx[s] = static_cast<uint8_t>(nl++);
+            const uint32_t prefix = cb->data[s] >> (len - p->lut_bits);
+            if (!of_lut[prefix] && n_sub < DEC_SUB_TABLES_MAX) of_lut[prefix] = static_cast<uint8_t>(++n_sub);
+            p->lut_sub[s] = of_lut[prefix];
+        }
+        if (len > p->step_bits) {
+            const uint32_t prefix = cb->data[s] >> (len - p->step_bits);
+            if (!of_step[prefix] && n_step < 15 && ((n_step + 1) << p->step_sub_bits) <= DEC_STEP_SUB_WORDS) of_step[prefix] = static_cast<uint8_t>(++n_step);
+            p->step_sub[s] = of_step[prefix];
+        }
+        if (len > p->wstep_bits) {
+            const uint32_t prefix = cb->data[s] >> (len - p->wstep_bits);
+            if (!of_w[prefix] && n_w < 254 && ((n_w + 1) << p->wstep_sub_bits) <= DEC_STEP_SUB_WORDS) of_w[prefix] = static_cast<uint8_t>(++n_w);
+            p->wstep_sub[s] = of_w[prefix];
+        }
+    }
+    p->n_long = nl;
+    p->n_sub = n_sub;
+    p->n_step_sub = n_step;
+    p->n_wstep_sub = n_w;
+}
+
 }  // namespace et

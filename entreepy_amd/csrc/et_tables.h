@@ -46,6 +46,24 @@ struct HostDecodeTables {
     uint32_t lut_bits, n_long, sub_bits, n_sub;
 };
 
+// What the HOST decides about a code table's decode tables -- index widths, which long codes get
+// which second-level table, the order of the long list -- handed to the device, which fills the
+// tables themselves (et_kernels.hip k_build_dec_tables: same entries as the builders below, which
+// stay as the reference the device's output is tested against, and as ET_DEC_TABLES_HOST=1).
+struct TablePlan {
+    uint32_t data[256];
+    uint8_t length[256];
+    uint8_t lut_sub[256];    // symbol longer than lut_bits: 1 + its second-level table in the older format (0: none)
+    uint8_t step_sub[256];   // ... in the step table
+    uint8_t wstep_sub[256];  // ... in the write-step table
+    uint8_t long_idx[256];   // ... its position in the long list
+    uint32_t lut_bits, n_long, sub_bits, n_sub, max_syms;
+    uint32_t step_bits, step_sub_bits, n_step_sub;
+    uint32_t wstep_bits, wstep_sub_bits, n_wstep_sub;
+    uint32_t pad_;
+};
+void plan_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t max_syms, uint32_t step_bits_max, uint32_t wstep_bits_max, TablePlan *plan);
+
 // Older-format tables: lut[1 << k], longc[2 * n_long], sub[n_sub << sub_bits]; k =
 // min(longest code, lut_bits_max).
 void build_decode_tables(const et_codebook *cb, uint32_t lut_bits_max, uint32_t max_syms, uint32_t *lut, uint32_t *longc, uint16_t *sub,

@@ -134,6 +134,12 @@ int et_last_codebook(const et_ctx *ctx, et_codebook *out);
  * files that fail this check instead of decoding whatever follows. */
 int et_check_magic(const uint8_t first4[4], const char **why);
 
+/* Diagnostics: build the decode lookup tables of `cb` both ways -- on the device (what every
+ * decode call does, from the host's plan) and with the host-side reference builders -- and compare
+ * them entry for entry.  ET_OK when identical; ET_ERR_FORMAT with *where = 1 first-level table,
+ * 2 long list, 3 second-level tables, 4 code lengths, 5 step table, 6 write-step table. */
+int et_selftest_decode_tables(et_ctx *ctx, const et_codebook *cb, int *where);
+
 /* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */
 int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols);
 

@@ -592,3 +592,40 @@ def test_cut_code_across_the_last_subsequence_boundary(ctx):
             assert ctx.decode(data) == O.decode(data), f"truncated to {T} bytes ({tail} in the last subsequence)"
             checked += 1
     assert checked > 1500
+
+
+def test_device_built_decode_tables_equal_the_host_builders(ctx):
+    """Every decode call fills its lookup tables on the device (k_build_dec_tables) from the
+    host's plan; et_selftest_decode_tables builds them with the host-side reference builders as
+    well (the ones tests/test_sanitizers.py checks against a brute-force decoder) and compares
+    entry for entry.  Code tables of every shape: few / many symbols, flat, skewed, geometric
+    (long codes, second-level tables, more long prefixes than table slots)."""
+    import ctypes
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+
+    rng = np.random.default_rng(4711)
+    checked = 0
+    for it in range(400):
+        hist = np.zeros(256, dtype=np.uint64)
+        k, mode = int(rng.integers(1, 257)), it % 5
+        idx = rng.choice(256, size=k, replace=False)
+        if mode == 0:
+            hist[idx] = rng.integers(1, 4, size=k)
+        elif mode == 1:
+            hist[idx] = rng.integers(1, 100_000, size=k)
+        elif mode == 2:
+            hist[idx] = np.uint64(1) << rng.integers(0, 31, size=k).astype(np.uint64)  # up to 32-bit codes
+        elif mode == 3:
+            hist[idx] = 7
+        else:
+            hist[idx] = (1.6 ** np.minimum(np.arange(k), 40)).astype(np.uint64) + 1
+        cb = E.Codebook.from_histogram(hist)
+        if cb.raw.max_length > 32 or cb.raw.n_coded == 0:
+            continue
+        where = ctypes.c_int(0)
+        rc = N.lib().et_selftest_decode_tables(ctx._h, ctypes.byref(cb.raw), ctypes.byref(where))
+        assert rc == N.ET_OK, f"iteration {it} (mode {mode}, {k} symbols, longest {cb.raw.max_length}): tables differ in part {where.value}"
+        checked += 1
+    assert checked > 300
