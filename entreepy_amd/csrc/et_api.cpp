@@ -838,10 +838,10 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     const bool can_speculate = cap >= n_symbols;
     bool wrote = false, write_ticket_zero = false;
     auto scan_and_total = [&](bool verify) -> int {
+        // (the scan's last thread stores the flags and the total straight into the pinned h_flags)
         et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
-                            verify ? sub_state : nullptr, blk_exit, flag + 2, first_bit);
+                            verify ? sub_state : nullptr, blk_exit, flag + 2, first_bit, flag, h_flags);
         ET_HIP(hipGetLastError());
-        ET_HIP(hipMemcpyAsync(h_flags, flag, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
         return ET_OK;
     };

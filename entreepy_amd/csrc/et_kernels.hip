@@ -267,7 +267,8 @@ __global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, u
 
 __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__restrict__ out, uint32_t n,
                                                       const unsigned long long *__restrict__ group_sum, unsigned long long base,
-                                                      uint32_t *__restrict__ zero_words, unsigned long long *__restrict__ total_copy) {
+                                                      uint32_t *__restrict__ zero_words, unsigned long long *__restrict__ total_copy,
+                                                      const uint32_t *__restrict__ report_src, uint32_t *__restrict__ report_dst) {
     __shared__ unsigned long long wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
@@ -288,8 +289,17 @@ __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__rest
     if (g == gridDim.x - 1 && tid == 0) {
         const unsigned long long total = prefix + group_sum[g];
         out[n] = total;
-        if (total_copy) *total_copy = total;  // next to the sweep flags: one read-back for the host
+        if (total_copy) *total_copy = total;  // next to the sweep flags
         if (zero_words) zero_words[total >> 5] = 0;
+        if (report_dst) {
+            // the decode's report to the host, stored straight into pinned host memory (no copy
+            // command between this kernel and the write kernel behind it): words 0..11 = the
+            // sweeps' flags, final since the kernels before this one; 12..13 = the symbol total
+            for (int k = 0; k < 12; ++k) report_dst[k] = report_src[k];
+            report_dst[12] = static_cast<uint32_t>(total);
+            report_dst[13] = static_cast<uint32_t>(total >> 32);
+            __threadfence_system();
+        }
     }
 }
 
@@ -2073,7 +2083,7 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
     const uint32_t groups = (n_tiles + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), 0xffffffffu);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr));
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr));
 }
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
@@ -2353,10 +2363,10 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
                      unsigned long long *blk_off, unsigned long long *total_copy, const uint32_t *verify_state, const uint32_t *verify_exit,
-                     uint32_t *verify_flag, uint32_t verify_first) {
+                     uint32_t *verify_flag, uint32_t verify_first, const uint32_t *report_src, uint32_t *report_dst) {
     const uint32_t groups = (n_blocks + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag, verify_first);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy);
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy, report_src, report_dst);
 }
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
