@@ -209,10 +209,9 @@ def main():
         m_bytes = state["body_bytes"]          # packed body bytes of this rank's shard
         sync_launches = phases["sync_launches"] / K
         kernels = {
-            # name: (ms per launch, algorithmic bytes per launch); HIP events on the ctx stream.
-            # hist also holds k_hist_reduce (~12 us); the sync and write figures include the
-            # few-workgroup launches for the stream's first/last blocks (k_dec_sync<true>,
-            # k_dec_write) that run beside them; the repair sweep (~0.02 ms) is in dec_sync.
+            # name: (ms per launch, algorithmic bytes per launch).  Each of the four kernels carries
+            # its own pair of HIP events on the ctx stream (hipExtLaunchKernelGGL: begin and end of
+            # that dispatch, no marker packets), recorded in every step of the timed region.
             "k_hist_tiles": (ms["hist"], n),
             "k_encode_tiles": (ms["enc_body"], n + m_bytes),
             "k_dec_sync_reg2": (ms["dec_sync_first"], m_bytes),
@@ -221,6 +220,8 @@ def main():
         dominant = max(kernels, key=lambda k: kernels[k][0])
         d_ms, d_bytes = kernels[dominant]
         achieved = d_bytes / (d_ms * 1e-3) / 1e9
+        # whole encode on the GPU's clock, begin of K1 to end of K4 (enc_scan = everything between the
+        # two: histogram reduce, the host's code construction, tile scan, uploads)
         enc_kernel_ms = ms["hist"] + ms["enc_scan"] + ms["enc_body"]
         out = {
             "metric": "GB/s encode+decode on 1 GiB text at 1/2/4/8 MI355X; % of HBM read peak",

@@ -198,6 +198,16 @@ void record(et_ctx *ctx, int i) {
 
 constexpr int EV_DEC = 6;
 
+// Events a timed kernel launch carries itself (begin = ev[a], end = ev[b]); none when timing is off.
+et::KernelEvents timed(et_ctx *ctx, int a, int b) {
+    et::KernelEvents e;
+    if (ctx->timing) {
+        e.start = ctx->ev[a];
+        e.stop = ctx->ev[b];
+    }
+    return e;
+}
+
 float elapsed(et_ctx *ctx, int a, int b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) ms = 0.f;
@@ -211,7 +221,7 @@ double now_ms() {
 int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) {
     ET_TRY(ensure_encode_ws(ctx, g.n_tiles));
     et::launch_hist(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<uint32_t *>(ctx->tile_hist.p),
-                    static_cast<unsigned long long *>(ctx->block_hist.p), static_cast<unsigned long long *>(ctx->hist.p));
+                    static_cast<unsigned long long *>(ctx->block_hist.p), static_cast<unsigned long long *>(ctx->hist.p), timed(ctx, 0, 1));
     ET_HIP(hipGetLastError());
     ctx->hist_text = d_text;
     ctx->hist_n = n;
@@ -225,7 +235,6 @@ int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) 
 int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *out32, uint64_t base_bit,
              const uint8_t *header, size_t header_len, int ev_scan, int ev_body) {
     const bool long_codes = cb->max_length > 32;
-    record(ctx, 4);
     for (int s = 0; s < 256; ++s) {
         const uint32_t len = cb->length[s];
         uint32_t code = cb->data[s];
@@ -245,11 +254,9 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
         const size_t padded = (header_len + 3) & ~static_cast<size_t>(3);
         ET_HIP(hipMemcpyAsync(out32, header, padded, hipMemcpyHostToDevice, ctx->stream));
     }
-    record(ctx, ev_scan);
     et::launch_encode(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<const unsigned long long *>(ctx->tile_off.p),
-                      static_cast<const uint2 *>(ctx->enc_table.p), cb->max_length, out32);
+                      static_cast<const uint2 *>(ctx->enc_table.p), cb->max_length, out32, timed(ctx, ev_scan, ev_body));  // K4 carries its two events
     ET_HIP(hipGetLastError());
-    record(ctx, ev_body);
     return ET_OK;
 }
 
@@ -317,7 +324,10 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     }
     ctx->h_lut = ctx->h_lut_buf[0];
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 16 * sizeof(uint64_t)) == hipSuccess;
-    for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    // timing-only events: no system-scope fence when they complete (hip_runtime_api.h: "for events that
+    // are only being used to measure timing"); with the default flags the ten records of an
+    // encode+decode cost ~65 us of cache write-backs and waits at 1 GiB
+    for (auto &e : ctx->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableSystemFence) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->ev_flags, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         et_ctx_destroy(ctx);
@@ -388,14 +398,15 @@ extern "C" int et_last_timings_of(et_ctx *ctx, int which, et_timings *out) {
             ctx->tm_enc.hist_ms = elapsed(ctx, 0, 1);
             ctx->tm_enc.total_ms = elapsed(ctx, 0, 3);
         }
-        ctx->tm_enc.scan_ms = ctx->pend_enc_bits ? elapsed(ctx, 4, 2) : 0.f;
+        ctx->tm_enc.scan_ms = ctx->pend_enc_bits ? elapsed(ctx, 1, 2) : 0.f;  // everything between K1 and K4: histogram reduce, host code construction, tile scan, uploads
         ctx->tm_enc.body_ms = elapsed(ctx, 2, 3);
         ctx->pend_enc = ctx->pend_enc_shard = false;
     }
     if (which == 1 && ctx->pend_dec) {
         ET_HIP(hipEventSynchronize(ctx->ev[EV_DEC + 3]));
-        ctx->tm_dec.sync_ms = elapsed(ctx, EV_DEC + 0, EV_DEC + 1);
-        ctx->tm_dec.scan_ms = elapsed(ctx, EV_DEC + 1, EV_DEC + 2);
+        // events 0/5 = begin/end of the first sweep's main kernel, 2/3 = of the write kernel
+        ctx->tm_dec.sync_ms = elapsed(ctx, EV_DEC + 0, EV_DEC + 2);  // everything before the write: sweeps, check, scan
+        ctx->tm_dec.scan_ms = elapsed(ctx, EV_DEC + 5, EV_DEC + 2);  // ... of which after the first sweep (repair sweep, verification, scan)
         ctx->tm_dec.body_ms = elapsed(ctx, EV_DEC + 2, EV_DEC + 3);
         ctx->tm_dec.total_ms = elapsed(ctx, EV_DEC + 0, EV_DEC + 3);
         ctx->tm_dec.sync_first_ms = ctx->pend_dec_first ? elapsed(ctx, EV_DEC + 0, EV_DEC + 5) : 0.f;
@@ -448,9 +459,7 @@ extern "C" int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, vo
         return ET_OK;
     }
     const Geometry g = make_geometry(ctx, d_text, n);
-    record(ctx, 0);
-    ET_TRY(run_histogram(ctx, d_text, n, g));
-    record(ctx, 1);
+    ET_TRY(run_histogram(ctx, d_text, n, g));  // (K1 carries events 0 and 1)
     ET_HIP(hipMemcpyAsync(d_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->timing) {
         ET_HIP(hipStreamSynchronize(ctx->stream));
@@ -526,9 +535,7 @@ extern "C" int et_encode_device(et_ctx *ctx, const void *d_text, size_t n, void 
     if (cap < et_encode_bound(n)) return fail(ctx, ET_ERR_CAP, "cap < et_encode_bound(n)");
     DeviceGuard guard(ctx->device);
     const Geometry g = make_geometry(ctx, d_text, n);
-    record(ctx, 0);
-    ET_TRY(run_histogram(ctx, d_text, n, g));
-    record(ctx, 1);
+    ET_TRY(run_histogram(ctx, d_text, n, g));  // (K1 carries events 0 and 1)
     ET_TRY(fetch_histogram(ctx));
     const double t1 = now_ms();
 
@@ -811,7 +818,6 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     bool flags_zeroed = false;
     ET_TRY(prepare_decode_tables(ctx, cb, &tb, &tb_write, static_cast<uint32_t *>(ctx->flag.p), &flags_zeroed));
     const double t1 = now_ms();
-    record(ctx, EV_DEC + 0);
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
     uint32_t *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
@@ -848,7 +854,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
         // speculative: the kernel itself looks at the sweeps' flags and does nothing if the state is not final
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
-                             write_ticket_zero, speculative ? flag : nullptr);
+                             write_ticket_zero, speculative ? flag : nullptr, timed(ctx, EV_DEC + 2, EV_DEC + 3));
         write_ticket_zero = false;
         ET_HIP(hipGetLastError());
         return ET_OK;
@@ -860,15 +866,12 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (!flags_zeroed) ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
         write_ticket_zero = true;
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
-                            et::DEC_HAVE_START, nullptr, nullptr, side, true);
-        record(ctx, EV_DEC + 5);
+                            et::DEC_HAVE_START, nullptr, nullptr, side, true, timed(ctx, EV_DEC + 0, EV_DEC + 5));
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
                             et::DEC_HAVE_START, worklist, flag + 8, side);
         ET_HIP(hipGetLastError());
         iters = 3;  // run-in sweep, repair sweep, verification
-        record(ctx, EV_DEC + 1);
         ET_TRY(scan_and_total(true));
-        record(ctx, EV_DEC + 2);
         if (can_speculate) {
             ET_TRY(write_symbols(n_symbols, true));
             wrote = true;
@@ -879,6 +882,10 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (!et::dec_state_final(h_flags[1], h_flags[2], n_blocks)) wrote = false;  // the speculative launch declined by the same rule
     }
     if (exhaustive) {
+        if (iters == 0) {  // no first sweep carried the events: plain markers in front of the exhaustive kernels
+            record(ctx, EV_DEC + 0);
+            record(ctx, EV_DEC + 5);
+        }
         const uint32_t n_starts = cb->max_length;
         const uint32_t stride = n_starts <= 8 ? 8 : (n_starts <= 16 ? 16 : 32);
         const size_t n_groups = (static_cast<size_t>(n_blocks) + 255) / 256;
@@ -906,16 +913,13 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (iters > n_blocks + 4) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
     }
     if (exhaustive || more_sweeps) {
-        record(ctx, EV_DEC + 1);
         ET_TRY(scan_and_total(false));
-        record(ctx, EV_DEC + 2);
         ET_HIP(hipEventSynchronize(ctx->ev_flags));
     }
     const uint64_t decodable = static_cast<uint64_t>(h_flags[12]) | (static_cast<uint64_t>(h_flags[13]) << 32);
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
     if (n_out && !wrote) ET_TRY(write_symbols(n_out, false));
-    record(ctx, EV_DEC + 3);
     *out_len = static_cast<size_t>(n_out);
     if (ctx->timing) {
         ctx->tm_dec = et_timings{};

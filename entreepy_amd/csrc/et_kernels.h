@@ -78,18 +78,23 @@ struct SideLane {
     hipEvent_t fork, join;
 };
 
+// Timing events carried by a launch itself (no marker packets): begin / end of that kernel.
+struct KernelEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
-                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist);
+                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, KernelEvents ev = {});
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
                       unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
                       unsigned long long *tile_off, uint32_t *out32);
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
-                   const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32);
+                   const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32, KernelEvents ev = {});
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket,
                      uint32_t flags = DEC_HAVE_START, uint32_t *worklist = nullptr, uint32_t *n_work = nullptr, const SideLane *side = nullptr,
-                     bool ticket_is_zero = false);
+                     bool ticket_is_zero = false, KernelEvents ev = {});  // ev: the first sweep's main kernel
 void launch_dec_maps(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, bool have_start, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t n_starts, uint32_t map_stride, uint8_t *lane_maps, uint8_t *blk_maps, uint8_t *grp_maps);
 void launch_dec_resolve(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, bool const_first, uint64_t n_subs,
@@ -112,6 +117,6 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr,
-                      bool ticket_is_zero = false, const uint32_t *void_flags = nullptr);
+                      bool ticket_is_zero = false, const uint32_t *void_flags = nullptr, KernelEvents ev = {});  // ev: the main write kernel
 
 }  // namespace et

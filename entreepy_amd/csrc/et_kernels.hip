@@ -20,6 +20,8 @@
 // leaves a 256-bin histogram and K4 gets a start bit offset.
 #include "et_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <hip/hip_runtime.h>
 
 namespace et {
@@ -2038,6 +2040,15 @@ static bool use_reg_kernels(uint32_t n_blocks) {
     return on && n_blocks > 3;  // (fewer: nothing but special blocks)
 }
 
+// A launch that carries its own timing events (hipExtLaunchKernelGGL: the dispatch's completion
+// signal records begin and end, no marker packets in the stream -- ten hipEventRecord markers per
+// encode+decode cost ~70 us at 1 GiB), or a plain launch when no events are asked for.
+#define ET_LAUNCH_TIMED(kernel_, grid_, block_, smem_, stream_, evs_, ...)                                                        \
+    do {                                                                                                                          \
+        if ((evs_).start || (evs_).stop) hipExtLaunchKernelGGL(kernel_, grid_, block_, smem_, stream_, (evs_).start, (evs_).stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel_, grid_, block_, smem_, stream_, __VA_ARGS__);                                             \
+    } while (0)
+
 // Grid of the tile-striding encode kernels: the workgroups the device holds at once
 // (occupancy query; both kernels use < 64 SGPRs, where the query is exact), so that
 // every workgroup gets within one tile of the same share.  ET_GRID_MODE=0: fixed 2048.
@@ -2063,13 +2074,13 @@ static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
 }
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
-                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist) {
+                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, KernelEvents ev) {
     // 4 workgroups per CU are resident (LDS): 1024 = one full batch (0.227 ms at 1 GiB; 2048 = two
     // batches 0.231; 1280 or 1536 = a full and a partial batch, 0.32-0.36)
     static const uint32_t want = [] { const char *e = getenv("ET_HIST_GRID"); return e && atoi(e) > 0 && atoi(e) <= static_cast<int>(MAX_GRID) ? static_cast<uint32_t>(atoi(e)) : 1024u; }();
     const uint32_t grid = n_tiles < want ? n_tiles : want;
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
-    hipLaunchKernelGGL(k_hist_tiles, dim3(grid), dim3(HIST_BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
+    ET_LAUNCH_TIMED(k_hist_tiles, dim3(grid), dim3(HIST_BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
     const uint32_t rgrid = grid < 512 ? grid : 512;
     hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
 }
@@ -2087,13 +2098,13 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
 }
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
-                   const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32) {
+                   const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32, KernelEvents ev) {
     if (max_len > 32)
-        hipLaunchKernelGGL(k_encode_tiles_long, dim3(tile_grid(k_encode_tiles_long, n_tiles)), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+        ET_LAUNCH_TIMED(k_encode_tiles_long, dim3(tile_grid(k_encode_tiles_long, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
     else if (max_len <= 31)  // a round emits at most 4096 * 31 / 32 + 2 words: fits a 4096-word ring
-        hipLaunchKernelGGL(k_encode_tiles<4096>, dim3(tile_grid(k_encode_tiles<4096>, n_tiles)), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+        ET_LAUNCH_TIMED(k_encode_tiles<4096>, dim3(tile_grid(k_encode_tiles<4096>, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
     else
-        hipLaunchKernelGGL(k_encode_tiles<8192>, dim3(tile_grid(k_encode_tiles<8192>, n_tiles)), dim3(BLOCK), 0, stream, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+        ET_LAUNCH_TIMED(k_encode_tiles<8192>, dim3(tile_grid(k_encode_tiles<8192>, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2274,7 +2285,7 @@ static void join_special(const SideLane *side, hipStream_t stream) {
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                      const DecodeTables &tb, uint32_t iter, uint32_t max_trips,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t *changed, uint32_t *ticket, uint32_t flags,
-                     uint32_t *worklist, uint32_t *n_work, const SideLane *side, bool ticket_is_zero) {
+                     uint32_t *worklist, uint32_t *n_work, const SideLane *side, bool ticket_is_zero, KernelEvents ev) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + SYNC_CHUNK - 1) / SYNC_CHUNK;
     const size_t smem = decode_smem_bytes(tb, false);
@@ -2287,19 +2298,19 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
             static const uint32_t chunk2 = [] { const char *e = getenv("ET_SYNC_REG2_TICKET"); return e && atoi(e) > 0 ? static_cast<uint32_t>(atoi(e)) : 4u; }();  // superblocks per ticket; measured 1 / 2 / 4 / 8 / 16: 0.54 / 0.37 / 0.35 / 0.37 / 0.44 ms
             fork_mark(side, stream);
-            hipLaunchKernelGGL(k_dec_sync_reg2, dim3(decode_grid(k_dec_sync_reg2, smem_reg, (n_blocks / 2 + chunk2 - 1) / chunk2, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk2);
+            ET_LAUNCH_TIMED(k_dec_sync_reg2, dim3(decode_grid(k_dec_sync_reg2, smem_reg, (n_blocks / 2 + chunk2 - 1) / chunk2, true)), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk2);
             const hipStream_t special = fork_special(side, stream);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(8), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY | DEC_SPECIAL_SUPER);
             join_special(side, stream);
         } else if (iter == 0 && ticketed) {
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
             fork_mark(side, stream);
-            hipLaunchKernelGGL((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+            ET_LAUNCH_TIMED((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             const hipStream_t special = fork_special(side, stream);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
             join_special(side, stream);
         } else if (iter == 0) {
-            hipLaunchKernelGGL((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+            ET_LAUNCH_TIMED((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         } else {
             if (worklist) {  // n_work zeroed by the caller
@@ -2315,7 +2326,7 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
     }
     if (SYNC_TICKET) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (iter == 0)
-        hipLaunchKernelGGL(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags);
+        ET_LAUNCH_TIMED(k_dec_sync<true>, dim3(decode_grid(k_dec_sync<true>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, ev, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags);
     else
         hipLaunchKernelGGL(k_dec_sync<false>, dim3(decode_grid(k_dec_sync<false>, smem, n_chunks, SYNC_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags);
 }
@@ -2372,7 +2383,7 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero,
-                      const uint32_t *void_flags) {
+                      const uint32_t *void_flags, KernelEvents ev) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
     const size_t smem = decode_smem_bytes(tb, true, false);
@@ -2380,13 +2391,13 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     if (use_reg_kernels(n_blocks)) {
         const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
         fork_mark(side, stream);
-        hipLaunchKernelGGL(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket, void_flags);
+        ET_LAUNCH_TIMED(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket, void_flags);
         const hipStream_t special = fork_special(side, stream);
         hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u, void_flags);
         join_special(side, stream);
         return;
     }
-    hipLaunchKernelGGL(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 0u, void_flags);
+    ET_LAUNCH_TIMED(k_dec_write, dim3(decode_grid(k_dec_write, smem, n_chunks, WRITE_TICKET)), dim3(BLOCK), smem, stream, ev, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 0u, void_flags);
 }
 
 }  // namespace et

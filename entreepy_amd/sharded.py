@@ -122,12 +122,15 @@ class ShardedCodec:
     def encode_timings(self):
         """Phase timings (ms) of the last encode_shard; waits for its last kernel.  With a
         group, "exchange" is the wall clock of the histogram all-gather including the wait
-        for K1 before it, and enc_total the sum of the phases."""
+        for K1 before it (host clock; on the GPU's clock it lies inside enc_scan), and
+        enc_total = hist + enc_scan + enc_body."""
         if self.group is None:
             return self.single_encode_timings()
         t = self.ctx.timings("encode")
         out = {"hist": t["hist_ms"], "enc_scan": t["scan_ms"], "enc_body": t["body_ms"], **self._host_timings}
-        out["enc_total"] = sum(out.values())
+        # scan_ms spans everything between K1 and K4 on the GPU's clock: histogram reduce, the exchange
+        # and the host's code construction (also listed on their own, host clock), tile scan, uploads
+        out["enc_total"] = out["hist"] + out["enc_scan"] + out["enc_body"]
         return out
 
     def single_encode_timings(self):

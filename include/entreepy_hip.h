@@ -49,15 +49,19 @@ typedef struct et_codebook {
     uint32_t max_length;     /* longest length */
 } et_codebook;
 
-/* Wall-clock split of the last whole call, in milliseconds (device phases from HIP
- * events on the ctx stream).  Replaces the -d "time taken" line (encode.zig:26-28). */
+/* Wall-clock split of the last whole call, in milliseconds.  Device phases come from HIP events on
+ * the ctx stream that the four large kernels carry themselves (begin and end of the histogram, pack,
+ * first synchronisation sweep and write kernels; no marker packets between the kernels).
+ * Replaces the -d "time taken" line (encode.zig:26-28). */
 typedef struct et_timings {
-    float hist_ms;      /* encode: byte histogram kernels */
-    float host_ms;      /* encode: D2H + tree/code build + H2D; decode: header parse + LUT build */
-    float scan_ms;      /* encode: tile bit totals + offset scan; decode: block count scan */
-    float body_ms;      /* encode: code scatter kernel; decode: symbol write kernel */
-    float sync_ms;      /* decode: self-synchronisation kernels */
-    float total_ms;     /* first to last event */
+    float hist_ms;      /* encode: the byte histogram kernel */
+    float host_ms;      /* encode: tree/code build on the host; decode: header parse + table plan */
+    float scan_ms;      /* encode: between the histogram and the pack kernel (reduce, host code construction, tile
+                           scan, uploads); decode: between the first sweep and the write kernel (repair sweep,
+                           verification, block count scan) */
+    float body_ms;      /* encode: code scatter (pack) kernel; decode: symbol write kernel */
+    float sync_ms;      /* decode: everything in front of the write kernel (sweeps, verification, scan) */
+    float total_ms;     /* begin of the first large kernel to the end of the last */
     uint32_t sync_iters;/* decode: synchronisation launches */
     uint32_t reserved;  /* decode: 1 when the exhaustive synchronisation path ran */
     float sync_first_ms;/* decode: the first synchronisation sweep alone (k_dec_sync<first>) */
