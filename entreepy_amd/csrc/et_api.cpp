@@ -68,8 +68,6 @@ struct et_ctx {
     uint8_t *h_header = nullptr;    // HEADER_STAGE
     uint32_t *h_lut = nullptr;      // the decode tables being built (one of h_lut_buf)
     uint32_t *h_lut_buf[2] = {};    // DEC_TABLES_BYTES each, used in turn: the host fills one while the other's upload may still be queued
-    hipEvent_t ev_lut[2] = {};      // recorded behind the upload from h_lut_buf[i]
-    bool lut_queued[2] = {};
     int lut_turn = 0;
     uint64_t *h_scalar = nullptr;   // 16: [1] a total, [2..3] flags (range decode), [4..11] the body decode's copy of flag[0..15]
 
@@ -320,7 +318,6 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
     for (int i = 0; i < 2; ++i) {
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut_buf[i]), DEC_TABLES_BYTES) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&ctx->ev_lut[i], hipEventDisableTiming) == hipSuccess;
     }
     ctx->h_lut = ctx->h_lut_buf[0];
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 16 * sizeof(uint64_t)) == hipSuccess;
@@ -349,8 +346,6 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
         if (b->p) (void)hipFree(b->p);
     delete ctx->io;
     void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_header, ctx->h_lut_buf[0], ctx->h_lut_buf[1], ctx->h_scalar};
-    for (auto &e : ctx->ev_lut)
-        if (e) (void)hipEventDestroy(e);
     for (void *p : pinned)
         if (p) (void)hipHostFree(p);
     for (auto &e : ctx->ev)
@@ -679,11 +674,11 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     // one pinned block, one device block, one upload: [first-level x 2 | long lists | second-level (+ lengths) x 2]
     ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
-    // Two pinned blocks used in turn: the upload from the one filled two calls ago is long done
-    // (its event says so), so the host builds these tables while the stream is still busy with
-    // whatever precedes this decode -- no stream-wide wait here.
+    // Two pinned blocks used in turn, and no wait here: every caller waits for something enqueued
+    // behind this upload before it returns (the decode for its flags, the range calls and the
+    // self-test for the stream), so the upload from the block filled two calls ago is long done and
+    // the host can fill this one while the stream is still busy with whatever precedes this decode.
     const int turn = ctx->lut_turn ^= 1;
-    if (ctx->lut_queued[turn]) ET_HIP(hipEventSynchronize(ctx->ev_lut[turn]));
     ctx->h_lut = ctx->h_lut_buf[turn];
     static const bool on_host = [] { const char *e = std::getenv("ET_DEC_TABLES_HOST"); return e && e[0] == '1'; }();  // A/B switch, and the reference the device's tables are tested against
     HostDecodeTables ht, hw;
@@ -746,8 +741,6 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
         ET_HIP(hipGetLastError());
         if (zeroed) *zeroed = zero16 != nullptr;
     }
-    ET_HIP(hipEventRecord(ctx->ev_lut[turn], ctx->stream));
-    ctx->lut_queued[turn] = true;
     return ET_OK;
 }
 
