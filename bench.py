@@ -241,7 +241,7 @@ def main():
                             f"(seed 0x5EED0004+rank), one step = encode to .et + decode back, HBM-resident",
                 "bytes_per_gpu": n,
                 "packed_bytes_per_gpu": m_bytes,
-                "sharding": "1 stream" if world == 1 else f"{world} contiguous shards of one stream, RCCL all-gather of the local histograms (sum = global histogram, rows = shard bit counts) + boundary-word all-gather",
+                "sharding": "1 stream" if world == 1 else f"{world} contiguous shards of one stream, one RCCL all-gather of the local histograms per step (sum = global histogram, rows = shard bit counts)",
                 "value_definition": "text bytes taken through encode+decode per second, all GPUs",
             },
             "encode_GBps": round(world * n / (ms["enc_total"] * 1e-3) / 1e9, 2),

@@ -83,9 +83,11 @@ SIGNATURES = {
     "et_encode_device": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "et_decode_device": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "et_histogram_device": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "et_histogram_on_host": (ctypes.c_int, [_vp, _vp]),
     "et_build_codebook": (ctypes.c_int, [_vp, _cbp]),
     "et_write_header": (ctypes.c_int, [_cbp, _u64, _vp, _sz, _szp]),
     "et_codebook_bits": (ctypes.c_int, [_cbp, _vp, _u64p]),
+    "et_plan_shards": (ctypes.c_int, [_vp, ctypes.c_uint32, _cbp, _vp, _sz, ctypes.POINTER(ctypes.c_size_t), _vp]),
     "et_encode_body_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _vp, _sz, _u64, _u64p]),
     "et_encode_head_shard_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, _vp, _sz, _vp, _sz, _u64p]),
     "et_parse_header": (ctypes.c_int, [_vp, _sz, _cbp, _u64p, _szp]),

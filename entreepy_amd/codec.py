@@ -251,6 +251,12 @@ class Context:
         assert hist.numel() == 256 and hist.element_size() == 8
         _check(N.lib().et_histogram_device(self._h, text.data_ptr(), text.numel(), hist.data_ptr()), self._h)
 
+    def histogram_on_host(self, counts):
+        """The counts of the last histogram_device call, already on the host (uint64[256])."""
+        c = np.ascontiguousarray(counts, dtype=np.uint64)
+        assert c.size == 256
+        _check(N.lib().et_histogram_on_host(self._h, c.ctypes.data), self._h)
+
     def encode_body_device(self, codebook, text, out, start_bit=0):
         end = ctypes.c_uint64(0)
         _check(N.lib().et_encode_body_device(self._h, ctypes.byref(codebook.raw), text.data_ptr(), text.numel(), out.data_ptr(),

@@ -512,6 +512,14 @@ int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t 
 
 }  // namespace
 
+extern "C" int et_histogram_on_host(et_ctx *ctx, const uint64_t counts[256]) {
+    if (!ctx || !counts) return ET_ERR_ARG;
+    if (!ctx->hist_text) return fail(ctx, ET_ERR_ARG, "no current histogram (et_histogram_device first)");
+    std::memcpy(ctx->h_hist, counts, 256 * sizeof(uint64_t));
+    ctx->hist_on_host = true;
+    return ET_OK;
+}
+
 extern "C" int et_encode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t n, void *d_out, size_t cap_bytes,
                                      uint64_t start_bit, uint64_t *end_bit) {
     return encode_shard(ctx, cb, d_text, n, d_out, cap_bytes, start_bit, nullptr, 0, end_bit);

@@ -194,6 +194,26 @@ extern "C" int et_write_header(const et_codebook *cb, uint64_t text_len, uint8_t
     return ET_OK;
 }
 
+extern "C" int et_plan_shards(const uint64_t *hists, uint32_t world, et_codebook *cb, uint8_t *header, size_t header_cap,
+                              size_t *header_len, uint64_t *start_bits) {
+    if (!hists || !world || !cb || !header || !header_len || !start_bits) return ET_ERR_ARG;
+    uint64_t total[256] = {0}, n = 0;
+    for (uint32_t r = 0; r < world; ++r)
+        for (int s = 0; s < 256; ++s) total[s] += hists[static_cast<size_t>(r) * 256 + s];
+    for (int s = 0; s < 256; ++s) n += total[s];
+    int rc = et_build_codebook(total, cb);
+    if (rc != ET_OK) return rc;
+    rc = et_write_header(cb, n, header, header_cap, header_len);
+    if (rc != ET_OK) return rc;
+    start_bits[0] = 8 * static_cast<uint64_t>(*header_len);
+    for (uint32_t r = 0; r < world; ++r) {
+        uint64_t bits = 0;
+        et_codebook_bits(cb, hists + static_cast<size_t>(r) * 256, &bits);
+        start_bits[r + 1] = start_bits[r] + bits;
+    }
+    return ET_OK;
+}
+
 extern "C" int et_codebook_bits(const et_codebook *cb, const uint64_t hist[256], uint64_t *bits) {
     if (!cb || !hist || !bits) return ET_ERR_ARG;
     uint64_t total = 0;

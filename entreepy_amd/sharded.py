@@ -30,15 +30,22 @@ from .codec import Codebook
 def plan_shards(hists):
     """hists: uint64 [world, 256] local histograms ->
     (codebook, header bytes, start_bits[world + 1]) with start_bits measured from bit 0
-    of the FILE (header included)."""
+    of the FILE (header included).  One library call (et_plan_shards): sum of the rows ->
+    code table (encode.zig:54-214) -> header -> every shard's body bits = sum of count x code
+    length.  Raises EmptyInputError when every shard is empty (encode.zig:137-138)."""
+    import ctypes
+
+    from . import _native as N
+    from .codec import _check
+
     hists = np.ascontiguousarray(hists, dtype=np.uint64)
-    total = hists.sum(axis=0, dtype=np.uint64)
-    cb = Codebook.from_histogram(total)  # raises EmptyInputError when every shard is empty (encode.zig:137-138)
-    header = cb.header(int(total.sum()))
-    starts = [8 * len(header)]
-    for h in hists:
-        starts.append(starts[-1] + cb.bits(h))
-    return cb, header, starts
+    world = hists.shape[0]
+    cb = Codebook()
+    header = np.empty(8192, dtype=np.uint8)
+    starts = np.empty(world + 1, dtype=np.uint64)
+    n = ctypes.c_size_t(0)
+    _check(N.lib().et_plan_shards(hists.ctypes.data, world, ctypes.byref(cb.raw), header.ctypes.data, header.size, ctypes.byref(n), starts.ctypes.data))
+    return cb, header[: n.value].tobytes(), [int(x) for x in starts]
 
 
 def piece_words(starts, r):
@@ -106,6 +113,8 @@ class ShardedCodec:
         cb, header, starts = plan_shards(hists)
         t_h1 = time.perf_counter()
         r = self.rank
+        if n and hasattr(ctx, "histogram_on_host"):
+            ctx.histogram_on_host(hists[r])  # this rank's row of the exchange: no second read-back in the shard encode
         if r == 0:
             end = ctx.encode_head_shard_device(cb, text, enc, header)
             local_start = starts[0]

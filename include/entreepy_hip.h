@@ -161,6 +161,11 @@ int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t len,
  * Also leaves per-tile histograms in the ctx for a following et_encode_body_device
  * on the SAME (d_text, n). */
 int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, void *d_hist256_u64);
+/* A caller that already holds the counts et_histogram_device produced for (d_text, n) on the host
+ * (a sharded encode reads them back for the exchange anyway) hands them over, and the shard encode
+ * that follows does not copy them from the device again.  ET_ERR_ARG unless a histogram of this ctx
+ * is current.  The counts must be the ones the device holds. */
+int et_histogram_on_host(et_ctx *ctx, const uint64_t counts[256]);
 
 /* encode.zig:54-214 + queue.zig:9-43 on the host: sort, two-queue tree, codes.
  * Bit-exact including the u8 book_index saturation (256 distinct symbols), the u32
@@ -175,6 +180,14 @@ int et_write_header(const et_codebook *cb, uint64_t text_len,
 /* Sum over s of hist[s] * length[s]: the body bit count of a shard, from its local
  * histogram alone (no data pass). */
 int et_codebook_bits(const et_codebook *cb, const uint64_t hist[256], uint64_t *bits);
+
+/* The host step of a sharded encode in one call: hists = world rows of 256 local counts (the
+ * all-gathered histograms, row r = shard r).  Their sum is the stream's histogram (encode.zig:43-47)
+ * -> code table, header (text_len = the sum of all counts), and start_bits[0..world]: shard r's body
+ * occupies file bits [start_bits[r], start_bits[r+1]), start_bits[0] = 8 * header_len.  Every rank
+ * computes the same plan from the same rows.  ET_ERR_EMPTY when every count is 0. */
+int et_plan_shards(const uint64_t *hists, uint32_t world, et_codebook *cb, uint8_t *header, size_t header_cap,
+                   size_t *header_len, uint64_t *start_bits);
 
 /* encode.zig:303-315 on the GPU for one shard: pack the codes of d_text[0..n) into
  * d_out as a MSB-first bitstream whose first bit lands at bit `start_bit` of d_out
