@@ -833,7 +833,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     // (on text ~0.4 % of the block boundaries); the scan that follows also verifies that
     // every block now starts where its predecessor ends (the "sweep that changes nothing").
     // Everything up to the write kernel is enqueued without waiting; the flags and the
-    // symbol total come back in ONE read and ONE synchronisation, and only if they say so
+    // symbol total reach the host with ONE synchronisation (stored into pinned memory by the scan, no copy), and only if they say so
     // (blocks that do not synchronise -> exhaustive path; verification failed -> more
     // sweeps) is the tail redone.  Device words: flag[0] sweep-1 changed, [1] blocks that
     // gave up, [2] verification failed, [4] / [5] tickets of D1 / D3, [8] worklist count,
