@@ -2,12 +2,12 @@
 virtual ranks on one GPU: random sources, sizes, rank counts and UNEVEN block ranges, clean
 and truncated streams; the exchange is done by hand as sharded.decode_cold does it.  The
 concatenated pieces must equal the oracle's decode.  Run under `timeout`.
-Usage: python tools/soak_cold.py SEED TRIALS"""
+Usage: python tests/soak/soak_cold.py SEED TRIALS"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 

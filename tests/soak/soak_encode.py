@@ -2,12 +2,12 @@
 geometric -> long codes, Fibonacci-like counts -> codes beyond 32 bits), random sizes, random
 tile geometry (et_ctx_set_tile_rounds), device entry with a misaligned input pointer, and the
 host entry; every .et image must equal oracle.encode's.  Also round-trips through the decoder.
-Usage: python tools/soak_encode.py SEED TRIALS [MAX_BYTES]"""
+Usage: python tests/soak/soak_encode.py SEED TRIALS [MAX_BYTES]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 

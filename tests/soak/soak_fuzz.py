@@ -2,12 +2,12 @@
 fixed-seed versions): corrupted bodies must decode to exactly what the oracle says, corrupted
 dictionaries must return an error or bounded output, and nothing may hang -- run it under
 `timeout`, progress goes to stdout once per 50 trials.
-Usage: python tools/soak_fuzz.py SEED TRIALS [MAX_BYTES]"""
+Usage: python tests/soak/soak_fuzz.py SEED TRIALS [MAX_BYTES]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 
 import entreepy_amd as E

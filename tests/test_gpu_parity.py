@@ -573,7 +573,7 @@ def test_cut_code_across_the_last_subsequence_boundary(ctx):
     """Truncated streams whose last 256-bit subsequence holds only 8 to 24 bits: when the
     code cut by the stream's end BEGINS in the subsequence before, the lane that runs off the
     stream must hand "the stream is over" to the last lane -- it once handed over bit 0, and the
-    last lane decoded the cut code's tail as one more symbol (found by tools/soak_fuzz.py).
+    last lane decoded the cut code's tail as one more symbol (found by tests/soak/soak_fuzz.py).
     A Zipf-like source (many 9..13-bit codes, so that cut codes are common); every such
     truncation of a 3-block stream, checked against the oracle."""
     import entreepy_amd as E
