@@ -629,3 +629,34 @@ def test_device_built_decode_tables_equal_the_host_builders(ctx):
         assert rc == N.ET_OK, f"iteration {it} (mode {mode}, {k} symbols, longest {cb.raw.max_length}): tables differ in part {where.value}"
         checked += 1
     assert checked > 300
+
+
+def test_phase_timings_are_consistent(ctx):
+    """et_last_timings_of after device calls with timing on: the large kernels carry their own
+    begin/end events (hipExtLaunchKernelGGL), the phases between them are differences of those.
+    Encode: hist + scan + body = total; decode: sync + body = total, the first sweep is part of
+    sync -- on the text path, and on the exhaustive path (no first sweep: marker events)."""
+    import torch
+
+    import entreepy_amd as E
+
+    c = E.Context(0)
+    c.use_torch_stream()
+    c.enable_timing(True)
+    for data, exhaustive in ((corpus.text_like(6_000_000, 3), False), (corpus.uniform(3_000_000, 4, 1, 201), True)):
+        text = torch.from_numpy(data).cuda()
+        enc = torch.zeros(E.encode_bound(data.size) + 64, dtype=torch.uint8, device="cuda")
+        dec = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            m = c.encode_device(text, enc)
+            k = c.decode_device(enc[4:m], dec)
+            te, td = c.timings("encode"), c.timings("decode")
+            assert k == data.size and torch.equal(dec[:k], text)
+            assert te["hist_ms"] > 0 and te["body_ms"] > 0 and te["scan_ms"] > 0
+            assert abs(te["hist_ms"] + te["scan_ms"] + te["body_ms"] - te["total_ms"]) < 0.02 * te["total_ms"] + 1e-3
+            assert td["exhaustive_sync"] == exhaustive
+            assert td["body_ms"] > 0 and td["sync_ms"] > 0 and 0.0 < td["total_ms"] < 50.0
+            assert abs(td["sync_ms"] + td["body_ms"] - td["total_ms"]) < 0.02 * td["total_ms"] + 1e-3
+            if not exhaustive:
+                assert 0 < td["sync_first_ms"] <= td["sync_ms"] * 1.001
+    c.close()
