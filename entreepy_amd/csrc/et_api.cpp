@@ -64,7 +64,7 @@ struct et_ctx {
 
     // pinned host staging
     uint64_t *h_hist = nullptr;     // 256
-    uint32_t *h_enc = nullptr;      // 768: {code,len} x 256, then len x 256
+    uint32_t *h_enc = nullptr;      // 768 words: {code,len} x 256, then len x 256; HEADER_STAGE bytes: the file header on its way to the image
     uint8_t *h_header = nullptr;    // HEADER_STAGE
     uint32_t *h_lut = nullptr;      // the decode tables being built (one of h_lut_buf)
     uint32_t *h_lut_buf[2] = {};    // DEC_TABLES_BYTES each, used in turn: the host fills one while the other's upload may still be queued
@@ -185,7 +185,7 @@ int ensure_encode_ws(et_ctx *ctx, uint32_t n_tiles) {
     ET_TRY(ensure(ctx, ctx->hist, 256 * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->tile_bits, (static_cast<size_t>(n_tiles) + 1) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->tile_off, (static_cast<size_t>(n_tiles) + 1) * sizeof(uint64_t)));
-    ET_TRY(ensure(ctx, ctx->enc_table, 768 * sizeof(uint32_t)));  // {code,len} x 256, then len x 256: one upload
+    ET_TRY(ensure(ctx, ctx->enc_table, 768 * sizeof(uint32_t) + HEADER_STAGE));  // {code,len} x 256, then len x 256, then the file header: one upload
     ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_tiles) / 1024 + 2) * sizeof(uint64_t)));
     return ET_OK;
 }
@@ -241,17 +241,22 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
         ctx->h_enc[2 * s + 1] = len;
         ctx->h_enc[512 + s] = len;
     }
-    ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 768 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    // The header rides behind the code table in ONE upload; the scan kernel copies it into the image
+    // once the word holding the header/body seam is zeroed (no copy command between K2 and K4).
+    const size_t padded = (header_len + 3) & ~static_cast<size_t>(3);
+    if (header_len) {
+        if (padded > HEADER_STAGE) return fail(ctx, ET_ERR_ARG, "header too long");
+        uint8_t *stage = reinterpret_cast<uint8_t *>(ctx->h_enc + 768);
+        std::memcpy(stage, header, header_len);
+        std::memset(stage + header_len, 0, padded - header_len);
+    }
+    ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 768 * sizeof(uint32_t) + padded, hipMemcpyHostToDevice, ctx->stream));
     et::launch_tile_scan(ctx->stream, static_cast<const uint32_t *>(ctx->tile_hist.p), g.n_tiles,
                          static_cast<const uint32_t *>(ctx->enc_table.p) + 512, static_cast<unsigned long long *>(ctx->tile_bits.p),
                          static_cast<unsigned long long *>(ctx->group_sum.p), base_bit,
-                         static_cast<unsigned long long *>(ctx->tile_off.p), out32);
+                         static_cast<unsigned long long *>(ctx->tile_off.p), out32, static_cast<const uint32_t *>(ctx->enc_table.p) + 768,
+                         static_cast<uint32_t>(padded / 4));
     ET_HIP(hipGetLastError());
-    if (header_len) {
-        // After the scan (which zeroes the word holding the header/body seam), before K4.
-        const size_t padded = (header_len + 3) & ~static_cast<size_t>(3);
-        ET_HIP(hipMemcpyAsync(out32, header, padded, hipMemcpyHostToDevice, ctx->stream));
-    }
     et::launch_encode(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<const unsigned long long *>(ctx->tile_off.p),
                       static_cast<const uint2 *>(ctx->enc_table.p), cb->max_length, out32, timed(ctx, ev_scan, ev_body));  // K4 carries its two events
     ET_HIP(hipGetLastError());
@@ -314,7 +319,7 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hist), 256 * sizeof(uint64_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 768 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 768 * sizeof(uint32_t) + HEADER_STAGE) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
     for (int i = 0; i < 2; ++i) {
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lut_buf[i]), DEC_TABLES_BYTES) == hipSuccess;

@@ -87,7 +87,7 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, KernelEvents ev = {});
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
                       unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
-                      unsigned long long *tile_off, uint32_t *out32);
+                      unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src = nullptr, uint32_t header_words = 0);  // header_src (device): the file header, copied to out32[0 .. header_words) behind the seam word's zeroing
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32, KernelEvents ev = {});
 void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, u
 __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__restrict__ out, uint32_t n,
                                                       const unsigned long long *__restrict__ group_sum, unsigned long long base,
                                                       uint32_t *__restrict__ zero_words, unsigned long long *__restrict__ total_copy,
-                                                      const uint32_t *__restrict__ report_src, uint32_t *__restrict__ report_dst) {
+                                                      const uint32_t *__restrict__ report_src, uint32_t *__restrict__ report_dst,
+                                                      const uint32_t *__restrict__ header_src, uint32_t header_words) {
     __shared__ unsigned long long wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
@@ -284,16 +285,21 @@ __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__rest
     unsigned long long prefix = base;
     for (int w = 0; w < 16; ++w) prefix += wsum[w];
     const uint32_t i = g * 1024 + tid;
+    // The word the first tile starts in (the header/body seam of a head shard) is zeroed by ONE
+    // thread, element 0's, so that the header can be copied over it below without a race: tiles
+    // that begin in the same word (zero-bit tiles: text of nothing but the symbol the reference
+    // drops, quirk Q1) and the stream's end leave it alone.
+    const unsigned long long seam = base >> 5;
     if (i < n) {
         const unsigned long long v = out[i] + prefix;
         out[i] = v;
-        if (zero_words) zero_words[v >> 5] = 0;
+        if (zero_words && ((v >> 5) != seam || i == 0)) zero_words[v >> 5] = 0;
     }
     if (g == gridDim.x - 1 && tid == 0) {
         const unsigned long long total = prefix + group_sum[g];
         out[n] = total;
         if (total_copy) *total_copy = total;  // next to the sweep flags
-        if (zero_words) zero_words[total >> 5] = 0;
+        if (zero_words && (total >> 5) != seam) zero_words[total >> 5] = 0;
         if (report_dst) {
             // the decode's report to the host, stored straight into pinned host memory (no copy
             // command between this kernel and the write kernel behind it): words 0..11 = the
@@ -303,6 +309,12 @@ __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__rest
             report_dst[13] = static_cast<uint32_t>(total >> 32);
             __threadfence_system();
         }
+    }
+    if (g == 0 && header_words) {
+        // the file header (header_src: behind the code table in its upload) goes into the output image once
+        // the seam word is zeroed (this group's thread 0, above; nobody else writes it in this kernel)
+        __syncthreads();
+        for (uint32_t k = tid; k < header_words; k += 1024) zero_words[k] = header_src[k];
     }
 }
 
@@ -2090,13 +2102,13 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
 
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
                       unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
-                      unsigned long long *tile_off, uint32_t *out32) {
+                      unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src, uint32_t header_words) {
     uint32_t grid = (n_tiles + 3) / 4;
     if (grid > MAX_GRID) grid = MAX_GRID;
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
     const uint32_t groups = (n_tiles + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), 0xffffffffu);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr));
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), header_src, header_words);
 }
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
@@ -2379,7 +2391,7 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
                      uint32_t *verify_flag, uint32_t verify_first, const uint32_t *report_src, uint32_t *report_dst) {
     const uint32_t groups = (n_blocks + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag, verify_first);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy, report_src, report_dst);
+    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy, report_src, report_dst, static_cast<const uint32_t *>(nullptr), 0u);
 }
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,

@@ -660,3 +660,20 @@ def test_phase_timings_are_consistent(ctx):
             if not exhaustive:
                 assert 0 < td["sync_first_ms"] <= td["sync_ms"] * 1.001
     c.close()
+
+
+def test_header_and_zero_bit_tiles_share_the_seam_word(ctx):
+    """All 256 byte values occur, so the reference drops the most frequent one (quirk Q1: code
+    length 0) -- and the text STARTS with 6 MiB of it: more than 1024 tiles (a whole scan group and
+    more) contribute no bits and all begin in the word that holds the header/body seam.  The scan
+    kernel copies the header over that word; only one thread may zero it."""
+    O = _oracle()
+    head = np.full(6 << 20, 7, dtype=np.uint8)
+    rest = np.tile(np.arange(256, dtype=np.uint8), 3000)
+    data = np.concatenate([head, rest])
+    ctx.set_tile_rounds(1)  # 4 KiB tiles: 1536 of them inside the run
+    try:
+        for _ in range(3):
+            assert ctx.encode(data) == O.encode(data)
+    finally:
+        ctx.set_tile_rounds(0)
