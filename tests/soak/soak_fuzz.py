@@ -23,6 +23,8 @@ def main():
     t0 = time.time()
     bad = errors = 0
     for trial in range(trials):
+        if trial % 97 == 0:
+            ctx.enable_timing(trial % 2 == 0)  # both launch flavours: with and without kernel-carried events
         n = int(rng.integers(20_000, max_bytes))
         src = int(rng.integers(0, 4))
         if src == 0:
