@@ -677,3 +677,20 @@ def test_header_and_zero_bit_tiles_share_the_seam_word(ctx):
             assert ctx.encode(data) == O.encode(data)
     finally:
         ctx.set_tile_rounds(0)
+
+
+def test_declared_length_shorter_or_longer_than_the_body(ctx):
+    """The header's length field (decode.zig:36-42) decides how many symbols come out: shorter
+    than what the body holds -> exactly that many (also 0, 1, block and subsequence boundaries);
+    longer -> everything the body holds, pad bits included if they happen to form a code (the format's
+    own ambiguity).  Against the oracle's intended decoder."""
+    O = _oracle()
+    rng = np.random.default_rng(99)
+    text = corpus.text_like(900_000, 17)
+    et = bytearray(O.encode(text)[4:])
+    lengths = [0, 1, 2, 255, 256, 257, 13_999, 14_000, 14_001, 450_000, 899_999, 900_000, 900_001, 5_000_000] + [int(x) for x in rng.integers(0, 900_000, size=20)]
+    for n_decl in lengths:
+        et[1:5] = int(n_decl).to_bytes(4, "big")
+        want = O.decode(bytes(et), cap=max(n_decl, 900_000) + 64)
+        assert min(n_decl, 900_000) <= len(want) <= min(n_decl, 900_002)  # (pad bits may hold one more short code)
+        assert ctx.decode(bytes(et)) == want, f"declared {n_decl}"
