@@ -12,6 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A fresh checkout holds no built artefacts (they are git-ignored): build the library, the CLI
+    # and the oracle once (what __graft_entry__.build() does) when hipcc is around.  On the GPU box
+    # the prebuilt files travel with the snapshot and nothing happens here.
+    lib = os.path.join(ROOT, "entreepy_amd", "libentreepy_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "entreepy_amd", "csrc"), "all"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
