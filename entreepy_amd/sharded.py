@@ -85,6 +85,8 @@ class ShardedCodec:
         self.coll_device = device if (group is None or dist.get_backend(group) == "nccl") else torch.device("cpu")
         self.hist = torch.zeros(256, dtype=torch.int64, device=device)
         self.all_hists = torch.zeros(self.world * 256, dtype=torch.int64, device=self.coll_device)
+        # the gathered counts come to the host through a pinned buffer (a pageable .cpu() costs ~10 us more per step)
+        self.h_hists = torch.zeros(self.world * 256, dtype=torch.int64).pin_memory() if self.coll_device.type == "cuda" else None
         self._hdr_len = {}
 
     # ------------------------------------------------------------------ encode
@@ -108,7 +110,12 @@ class ShardedCodec:
         ctx.histogram_device(text, self.hist)
         t_x0 = time.perf_counter()
         dist.all_gather_into_tensor(self.all_hists, self.hist.to(self.coll_device), group=self.group)
-        hists = self.all_hists.view(self.world, 256).cpu().numpy().astype(np.uint64)
+        if self.h_hists is not None:
+            self.h_hists.copy_(self.all_hists, non_blocking=True)
+            torch.cuda.current_stream(self.coll_device).synchronize()
+            hists = self.h_hists.numpy().view(np.uint64).reshape(self.world, 256).copy()
+        else:
+            hists = self.all_hists.view(self.world, 256).numpy().astype(np.uint64)
         t_x1 = time.perf_counter()
         cb, header, starts = plan_shards(hists)
         t_h1 = time.perf_counter()
