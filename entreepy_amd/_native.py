@@ -8,10 +8,11 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ET_LIB_PATH: load another build of the same library (A/B variants in tools/ab_variants.sh)
+# ET_LIB_PATH: load another build of the same library (A/B runs of two builds in one tree)
 LIB_PATH = os.environ.get("ET_LIB_PATH") or os.path.join(_HERE, "libentreepy_hip.so")
 
-ET_OK, ET_ERR_EMPTY, ET_ERR_NOMEM, ET_ERR_CAP, ET_ERR_FORMAT, ET_ERR_HIP, ET_ERR_ARG, ET_ERR_UNSUPPORTED, ET_ERR_IO = range(9)
+ET_OK, ET_ERR_EMPTY, ET_ERR_NOMEM, ET_ERR_CAP, ET_ERR_FORMAT, ET_ERR_HIP, ET_ERR_ARG, ET_ERR_UNSUPPORTED, ET_ERR_IO, ET_ERR_RCCL = range(10)
+ET_RCCL_ID_BYTES = 128
 
 
 class Codebook(ctypes.Structure):
@@ -52,6 +53,30 @@ class RangeInfo(ctypes.Structure):
     ]
 
 
+class ShardInfo(ctypes.Structure):
+    """struct et_shard_info: where a rank's shard sits in the .et image."""
+
+    _fields_ = [
+        ("start_bit", ctypes.c_uint64),
+        ("end_bit", ctypes.c_uint64),
+        ("local_start_bit", ctypes.c_uint64),
+        ("header_len", ctypes.c_uint64),
+        ("file_bytes", ctypes.c_uint64),
+        ("text_len", ctypes.c_uint64),
+        ("piece_word_lo", ctypes.c_uint64),
+        ("piece_word_hi", ctypes.c_uint64),
+        ("owned_word_lo", ctypes.c_uint64),
+        ("owned_word_hi", ctypes.c_uint64),
+        ("exchange_ms", ctypes.c_float),
+        ("plan_ms", ctypes.c_float),
+        ("seam_ms", ctypes.c_float),
+        ("concat_ms", ctypes.c_float),
+    ]
+
+
+# int (*et_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
 _vp, _sz, _u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64
 _szp = ctypes.POINTER(ctypes.c_size_t)
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -72,6 +97,7 @@ SIGNATURES = {
     "et_last_error": (ctypes.c_char_p, [_vp]),
     "et_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "et_version": (ctypes.c_char_p, []),
+    "et_prefix_collisions": (ctypes.c_int, [_cbp, _vp, _sz, _szp]),
     "et_check_magic": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p)]),
     "et_selftest_decode_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Codebook), ctypes.POINTER(ctypes.c_int)]),
     "et_encode_bound": (_sz, [_sz]),
@@ -96,6 +122,26 @@ SIGNATURES = {
     "et_decode_range_resolve": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.POINTER(RangeInfo)]),
     "et_decode_range_write": (ctypes.c_int, [_vp, _u64, _vp, _sz, _szp]),
     "et_decode_body_device": (ctypes.c_int, [_vp, _cbp, _vp, _sz, ctypes.c_uint32, _u64, _vp, _sz, _szp]),
+    "et_ctx_stream": (_vp, [_vp]),
+    "et_ctx_device": (ctypes.c_int, [_vp]),
+    "et_device_to_fd": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int, _u64]),
+    "et_fd_to_device": (ctypes.c_int, [_vp, ctypes.c_int, _u64, _sz, _vp]),
+    "et_group_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ALLGATHER_FN, _vp, ctypes.POINTER(_vp)]),
+    "et_rccl_unique_id": (ctypes.c_int, [_vp]),
+    "et_group_create_rccl": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
+    "et_group_destroy": (None, [_vp]),
+    "et_group_last_error": (ctypes.c_char_p, [_vp]),
+    "et_encode_sharded": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, ctypes.POINTER(ShardInfo)]),
+    "et_shard_merge_seams": (ctypes.c_int, [_vp, _vp]),
+    "et_shard_write_fd": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "et_shard_place": (ctypes.c_int, [_vp, _vp, _vp, _sz]),
+    "et_shard_gather": (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int]),
+    "et_group_codebook": (ctypes.c_int, [_vp, _cbp]),
+    "et_group_start_bits": (ctypes.c_int, [_vp, _vp]),
+    "et_group_last_info": (ctypes.c_int, [_vp, ctypes.POINTER(ShardInfo)]),
+    "et_shard_words": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, _vp]),
+    "et_seam_word": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int)]),
+    "et_decode_sharded": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, _szp, _u64p]),
 }
 
 _lib = None

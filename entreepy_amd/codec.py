@@ -190,6 +190,12 @@ class Context:
         d["exhaustive_sync"] = bool(t.reserved)
         return d
 
+    def last_codebook(self):
+        """Code table of the most recent encode of this context (et_last_codebook)."""
+        cb = Codebook()
+        _check(N.lib().et_last_codebook(self._h, ctypes.byref(cb.raw)), self._h)
+        return cb
+
     # -- whole calls, files (chunked pinned-buffer pipeline) -------------------------
     def encode_file(self, in_path, out_path=None):
         """c: in_path -> out_path (.et image); out_path None = code only (main.zig -t).
@@ -311,6 +317,123 @@ class Context:
         n = ctypes.c_size_t(0)
         _check(N.lib().et_decode_range_write(self._h, int(max_symbols), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
         return n.value
+
+
+class Group:
+    """One rank's et_group: a Context plus how the ranks exchange small host buffers.
+
+    allgather: callable(bytes of this rank) -> bytes of all ranks in rank order (any transport:
+    torch.distributed over gloo, MPI, threads ...), or rccl_id: the 128-byte id rank 0 got from
+    Group.rccl_unique_id(), for an RCCL communicator of the library's own over xGMI."""
+
+    def __init__(self, ctx, rank, world, allgather=None, rccl_id=None):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self._h = ctypes.c_void_p()
+        self._py_gather = allgather
+        self._cb = N.ALLGATHER_FN(self._gather)  # kept alive with the group
+        if rccl_id is not None:
+            ident = (ctypes.c_uint8 * N.ET_RCCL_ID_BYTES).from_buffer_copy(bytes(rccl_id))
+            _check(N.lib().et_group_create_rccl(ctx._h, rank, world, ctypes.byref(ident), ctypes.byref(self._h)), ctx._h)
+        else:
+            _check(N.lib().et_group_create(ctx._h, rank, world, self._cb if allgather else ctypes.cast(None, N.ALLGATHER_FN), None, ctypes.byref(self._h)), ctx._h)
+
+    @staticmethod
+    def rccl_unique_id():
+        ident = (ctypes.c_uint8 * N.ET_RCCL_ID_BYTES)()
+        _check(N.lib().et_rccl_unique_id(ctypes.byref(ident)))
+        return bytes(ident)
+
+    def _gather(self, user, send, recv, nbytes):
+        try:
+            got = self._py_gather(ctypes.string_at(send, nbytes))
+            if len(got) != nbytes * self.world:
+                return 1
+            ctypes.memmove(recv, got, len(got))
+            return 0
+        except Exception:  # noqa: BLE001 -- reported to the C caller as a failed exchange
+            return 1
+
+    def _ck(self, status):
+        if status == N.ET_OK:
+            return
+        detail = N.lib().et_group_last_error(self._h).decode()
+        if status == N.ET_ERR_EMPTY:
+            raise EmptyInputError(status, detail)
+        raise EntreepyError(status, detail)
+
+    def close(self):
+        if self._h:
+            N.lib().et_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _info(i):
+        return {k: getattr(i, k) for k, _ in N.ShardInfo._fields_}
+
+    def encode_sharded(self, text, out):
+        """et_encode_sharded: this rank's chunk (uint8 CUDA tensor, may be empty) -> its piece of the image in `out`."""
+        i = N.ShardInfo()
+        self._ck(N.lib().et_encode_sharded(self._h, text.data_ptr() if text.numel() else None, text.numel(), out.data_ptr(), out.numel(), ctypes.byref(i)))
+        return self._info(i)
+
+    def merge_seams(self, out):
+        self._ck(N.lib().et_shard_merge_seams(self._h, out.data_ptr()))
+
+    def write_fd(self, out, fd):
+        self._ck(N.lib().et_shard_write_fd(self._h, out.data_ptr(), fd))
+
+    def place(self, out, image):
+        self._ck(N.lib().et_shard_place(self._h, out.data_ptr(), image.data_ptr(), image.numel()))
+
+    def gather(self, out, image, root=0):
+        self._ck(N.lib().et_shard_gather(self._h, out.data_ptr(), image.data_ptr() if image is not None else None,
+                                         image.numel() if image is not None else 0, root))
+
+    def info(self):
+        i = N.ShardInfo()
+        self._ck(N.lib().et_group_last_info(self._h, ctypes.byref(i)))
+        return self._info(i)
+
+    def codebook(self):
+        cb = Codebook()
+        self._ck(N.lib().et_group_codebook(self._h, ctypes.byref(cb.raw)))
+        return cb
+
+    def start_bits(self):
+        a = np.zeros(self.world + 1, dtype=np.uint64)
+        self._ck(N.lib().et_group_start_bits(self._h, a.ctypes.data))
+        return [int(x) for x in a]
+
+    def decode_sharded(self, compressed_text, out):
+        """et_decode_sharded: this rank's block range of one cold stream -> (symbols written, index of the first)."""
+        n = ctypes.c_size_t(0)
+        first = ctypes.c_uint64(0)
+        self._ck(N.lib().et_decode_sharded(self._h, compressed_text.data_ptr(), compressed_text.numel(), out.data_ptr(), out.numel(),
+                                           ctypes.byref(n), ctypes.byref(first)))
+        return n.value, first.value
+
+
+def shard_words(starts, world, rank):
+    """et_shard_words: (piece_lo, piece_hi, owned_lo, owned_hi) of `rank`, in 4-byte words of the image."""
+    a = np.ascontiguousarray(starts, dtype=np.uint64)
+    w = np.zeros(4, dtype=np.uint64)
+    _check(N.lib().et_shard_words(a.ctypes.data, world, rank, w.ctypes.data))
+    return tuple(int(x) for x in w)
+
+
+def seam_word(starts, world, rank, first_last):
+    """et_seam_word: the word closing `rank`'s owned range merged with the later shards that begin in it, or None."""
+    a = np.ascontiguousarray(starts, dtype=np.uint64)
+    fl = np.ascontiguousarray(first_last, dtype=np.uint32)
+    merged, has = ctypes.c_uint32(0), ctypes.c_int(0)
+    _check(N.lib().et_seam_word(a.ctypes.data, world, rank, fl.ctypes.data, ctypes.byref(merged), ctypes.byref(has)))
+    return merged.value if has.value else None
 
 
 _default_ctx = {}

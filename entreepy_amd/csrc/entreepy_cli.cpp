@@ -8,12 +8,17 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <hip/hip_runtime.h>
+
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -45,6 +50,7 @@ enum class Mode { None, Compress, Decompress };
 
 struct Options {
     bool print = false, debug = false, dry = false;
+    int gpus = 1;  // --gpus N (not in the reference): shard the file over N GPUs of the node
     Mode mode = Mode::None;
     std::string in_path, out_path;
     bool have_in = false;
@@ -62,7 +68,7 @@ std::string format_file_size(float byte_count) {
 
 // main.zig:73-146.  Returns 0 to continue, 1 to exit successfully (help), 2 on error.
 int parse_cli(int argc, char **argv, Options &o) {
-    enum { Normal, OutPath, InPath } state = Normal;
+    enum { Normal, OutPath, InPath, Gpus } state = Normal;
     if (argc <= 1) {  // main.zig:148-152
         std::fputs(kHelp, stdout);
         return 1;
@@ -87,6 +93,7 @@ int parse_cli(int argc, char **argv, Options &o) {
                                 else if (name == "debug") o.debug = true;
                                 else if (name == "test") o.dry = true;
                                 else if (name == "output") state = OutPath;
+                                else if (name == "gpus") state = Gpus;
                                 else { std::fprintf(stderr, "error: invalid option: %s\n\n", arg.c_str()); return 2; }
                                 stop = true;
                                 break;
@@ -104,6 +111,11 @@ int parse_cli(int argc, char **argv, Options &o) {
                 break;
             case InPath: o.in_path = arg; o.have_in = true; state = Normal; break;
             case OutPath: o.out_path = arg; state = Normal; break;
+            case Gpus:
+                o.gpus = std::atoi(arg.c_str());
+                if (o.gpus < 1 || o.gpus > 64) { std::fprintf(stderr, "error: invalid --gpus: %s\n\n", arg.c_str()); return 2; }
+                state = Normal;
+                break;
         }
     }
     if (o.mode == Mode::None) return 1;
@@ -156,6 +168,149 @@ void dump_dictionary(const et_codebook &cb) {  // encode.zig:204-212
     }
 }
 
+// encode.zig:221-247, the -d self-check (the loop itself: et_prefix_collisions); no newline, as there.
+void check_prefix_collisions(const et_codebook &cb) {
+    std::vector<uint8_t> pairs(2 * 256 * 255);
+    size_t n = 0;
+    if (et_prefix_collisions(&cb, pairs.data(), pairs.size() / 2, &n) != ET_OK) return;
+    for (size_t k = 0; k < n; ++k)
+        std::printf("Found colliding prefix codes for %u %c and %u %c", pairs[2 * k], static_cast<int>(pairs[2 * k]), pairs[2 * k + 1], static_cast<int>(pairs[2 * k + 1]));
+}
+
+// ---- --gpus N: one file over N GPUs ---------------------------------------------------------------
+// One host thread per rank, each with its own et_ctx (rank r on device r modulo the devices present, so the
+// path also runs on a one-GPU box); the ranks' exchange is an all-gather through this process's memory.
+struct ThreadExchange {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 1, arrived = 0, generation = 0;
+    std::vector<uint8_t> slots;
+    static int gather(void *user, const void *send, void *recv, size_t bytes) {
+        auto *x = static_cast<std::pair<ThreadExchange *, int> *>(user);
+        ThreadExchange &e = *x->first;
+        std::unique_lock<std::mutex> lk(e.m);
+        if (e.slots.size() < bytes * e.world) e.slots.resize(bytes * e.world);
+        std::memcpy(e.slots.data() + bytes * x->second, send, bytes);
+        const int gen = e.generation;
+        if (++e.arrived == e.world) {  // last in: everybody's bytes are there
+            e.arrived = 0;
+            ++e.generation;
+            e.cv.notify_all();
+        } else {
+            e.cv.wait(lk, [&] { return e.generation != gen; });
+        }
+        std::memcpy(recv, e.slots.data(), bytes * e.world);
+        // nobody may overwrite a slot before all have copied: a second rendezvous
+        const int gen2 = e.generation;
+        if (++e.arrived == e.world) {
+            e.arrived = 0;
+            ++e.generation;
+            e.cv.notify_all();
+        } else {
+            e.cv.wait(lk, [&] { return e.generation != gen2; });
+        }
+        return 0;
+    }
+};
+
+struct RankResult {
+    int rc = ET_OK;
+    std::string err;
+    size_t out_bytes = 0;  // bytes this rank contributed
+    et_codebook cb = {};
+};
+
+int run_sharded(const Options &opt, int in_fd, int out_fd, size_t *in_size, size_t *written, et_codebook *cb_out, std::string *err) {
+    struct stat_holder { off_t size; } st{::lseek(in_fd, 0, SEEK_END)};
+    if (st.size < 0) { *err = "input is not a regular file"; return ET_ERR_IO; }
+    const size_t file_size = static_cast<size_t>(st.size);
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) { *err = "no HIP device"; return ET_ERR_HIP; }
+    const int world = opt.gpus;
+    ThreadExchange ex;
+    ex.world = world;
+    std::vector<RankResult> res(world);
+    std::vector<std::thread> threads;
+    const bool compress = opt.mode == Mode::Compress;
+    const size_t skip = compress ? 0 : 4;
+    if (!compress && file_size < 9) { *err = "file shorter than its header"; return ET_ERR_FORMAT; }
+    *in_size = file_size - skip;
+    for (int r = 0; r < world; ++r) {
+        threads.emplace_back([&, r] {
+            RankResult &out = res[r];
+            std::pair<ThreadExchange *, int> who(&ex, r);
+            et_ctx *ctx = nullptr;
+            et_group *grp = nullptr;
+            void *d_in = nullptr, *d_out = nullptr;
+            auto bail = [&](int rc, const char *what) {
+                out.rc = rc;
+                out.err = std::string(what) + ": " + (grp && *et_group_last_error(grp) ? et_group_last_error(grp) : (ctx ? et_last_error(ctx) : ""));
+            };
+            const int dev = r % n_dev;
+            int rc = et_ctx_create(dev, &ctx);
+            // (every rank must keep making the same exchanges, so an early failure still walks through them)
+            bool ok = rc == ET_OK;
+            if (!ok) bail(rc, "et_ctx_create");
+            if (ok && (rc = et_group_create(ctx, r, world, ThreadExchange::gather, &who, &grp)) != ET_OK) { bail(rc, "et_group_create"); ok = false; }
+            if (ok) (void)hipSetDevice(dev);
+            if (compress) {
+                const size_t lo = file_size * r / world, hi = file_size * (r + 1) / world, n = hi - lo;
+                const size_t cap = et_encode_bound(n);
+                if (ok && (hipMalloc(&d_in, n + 16) != hipSuccess || hipMalloc(&d_out, cap + 16) != hipSuccess)) { bail(ET_ERR_NOMEM, "hipMalloc"); ok = false; }
+                if (ok && (rc = et_fd_to_device(ctx, in_fd, lo, n, d_in)) != ET_OK) { bail(rc, "reading the input"); ok = false; }
+                et_shard_info info{};
+                if (ok) {
+                    if ((rc = et_encode_sharded(grp, d_in, n, d_out, cap, &info)) != ET_OK) bail(rc, "et_encode_sharded");
+                    else if ((rc = et_shard_merge_seams(grp, d_out)) != ET_OK) bail(rc, "et_shard_merge_seams");
+                    else if (out_fd >= 0 && (rc = et_shard_write_fd(grp, d_out, out_fd)) != ET_OK) bail(rc, "et_shard_write_fd");
+                    if (rc == ET_OK) {
+                        const uint64_t lo_b = info.owned_word_lo * 4, hi_b = std::min<uint64_t>(info.owned_word_hi * 4, info.file_bytes);
+                        out.out_bytes = hi_b > lo_b ? static_cast<size_t>(hi_b - lo_b) : 0;
+                        et_group_codebook(grp, &out.cb);
+                    }
+                } else {  // keep the others from waiting forever on this rank's part of the exchanges
+                    uint8_t zero[2048] = {0};
+                    std::vector<uint8_t> sink(2048 * static_cast<size_t>(world));
+                    ThreadExchange::gather(&who, zero, sink.data(), 2048);
+                    ThreadExchange::gather(&who, zero, sink.data(), 8);
+                }
+            } else {
+                const size_t len = file_size - 4;
+                if (ok && hipMalloc(&d_in, len + 32) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc"); ok = false; }
+                if (ok && (rc = et_fd_to_device(ctx, in_fd, 4, len, d_in)) != ET_OK) { bail(rc, "reading the input"); ok = false; }  // main.zig:204: text_in[4..]
+                uint8_t head[9] = {0};
+                size_t n_symbols = 0;
+                if (ok && (::pread(in_fd, head, 9, 0) != 9 || et_decoded_size(head + 4, 5, &n_symbols) != ET_OK)) { bail(ET_ERR_FORMAT, "header"); ok = false; }
+                // a rank's share of the output is at most its share of the blocks' symbols: size for the whole text, lazily
+                if (ok && hipMalloc(&d_out, n_symbols + 64) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc"); ok = false; }
+                size_t wrote = 0;
+                uint64_t first = 0;
+                if (ok) {
+                    if ((rc = et_decode_sharded(grp, d_in, len, d_out, n_symbols + 64, &wrote, &first)) != ET_OK) bail(rc, "et_decode_sharded");
+                    else if (out_fd >= 0 && wrote && (rc = et_device_to_fd(ctx, d_out, wrote, out_fd, first)) != ET_OK) bail(rc, "writing the output");
+                    if (rc == ET_OK) out.out_bytes = wrote;
+                }
+            }
+            if (ctx) (void)hipStreamSynchronize(static_cast<hipStream_t>(et_ctx_stream(ctx)));
+            if (d_in) (void)hipFree(d_in);
+            if (d_out) (void)hipFree(d_out);
+            if (grp) et_group_destroy(grp);
+            if (ctx) et_ctx_destroy(ctx);
+        });
+    }
+    for (auto &t : threads) t.join();
+    *written = 0;
+    for (const RankResult &r : res) {
+        if (r.rc != ET_OK) {
+            *err = r.err;
+            return r.rc;
+        }
+        *written += r.out_bytes;
+    }
+    *cb_out = res[0].cb;
+    return ET_OK;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -190,12 +345,33 @@ int main(int argc, char **argv) {
 
     const auto t0 = std::chrono::steady_clock::now();
     size_t written = 0, reported = 0, in_size_bytes = 0;
-    if (opt.mode == Mode::Compress) {
+    std::string sharded_err;
+    if (opt.gpus > 1 && !(opt.mode == Mode::Decompress && opt.print)) {
+        if (opt.mode == Mode::Decompress && !magic_ok(in_fd, ctx)) {
+            rc = ET_ERR_FORMAT;
+        } else {
+            et_codebook cb{};
+            rc = run_sharded(opt, in_fd, out_fd, &in_size_bytes, &written, &cb, &sharded_err);
+            if (rc == ET_OK && opt.mode == Mode::Compress) {
+                if (opt.debug) {
+                    dump_dictionary(cb);
+                    check_prefix_collisions(cb);
+                    std::printf("\nbits in output: %zu\n", written * 8);
+                }
+                reported = written;
+            } else if (rc == ET_OK && !opt.dry) {
+                reported = written;
+            }
+        }
+    } else if (opt.mode == Mode::Compress) {
         rc = et_encode_fd(ctx, in_fd, out_fd, &in_size_bytes, &written);  // encode.zig:319: bytes land in the file
         if (rc == ET_OK) {
             if (opt.debug) {
                 et_codebook cb;
-                if (et_last_codebook(ctx, &cb) == ET_OK) dump_dictionary(cb);
+                if (et_last_codebook(ctx, &cb) == ET_OK) {
+                    dump_dictionary(cb);
+                    check_prefix_collisions(cb);
+                }
             }
             if (opt.debug) std::printf("\nbits in output: %zu\n", written * 8);  // encode.zig:320
             reported = written;  // encode.zig:331,336: counts the bytes even with -t
@@ -230,7 +406,8 @@ int main(int argc, char **argv) {
         }
     }
     if (rc != ET_OK) {
-        std::fprintf(stderr, "error: %s: %s\n", et_strerror(rc), g_magic_why.empty() ? et_last_error(ctx) : g_magic_why.c_str());
+        std::fprintf(stderr, "error: %s: %s\n", et_strerror(rc),
+                     !g_magic_why.empty() ? g_magic_why.c_str() : (!sharded_err.empty() ? sharded_err.c_str() : et_last_error(ctx)));
         et_ctx_destroy(ctx);
         ::close(in_fd);
         if (out_fd >= 0) ::close(out_fd);

@@ -287,6 +287,7 @@ extern "C" const char *et_strerror(int status) {
         case ET_ERR_ARG: return "invalid argument";
         case ET_ERR_UNSUPPORTED: return "unsupported stream (code length > 32)";
         case ET_ERR_IO: return "file read/write error";
+        case ET_ERR_RCCL: return "RCCL / exchange failure";
         default: return "unknown status";
     }
 }
@@ -303,14 +304,6 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     et_ctx *ctx = new (std::nothrow) et_ctx();
     if (!ctx) return ET_ERR_NOMEM;
     ctx->device = device;
-    if (const char *env = std::getenv("ET_DEC_STEP_BITS")) {
-        const long v = std::strtol(env, nullptr, 10);
-        if (v >= 8 && v <= static_cast<long>(et::DEC_STEP_BITS_MAX)) ctx->step_bits = static_cast<uint32_t>(v);
-    }
-    if (const char *env = std::getenv("ET_DEC_LUT_BITS_WRITE")) {
-        const long v = std::strtol(env, nullptr, 10);
-        if (v >= 8 && v <= static_cast<long>(et::DEC_LUT_BITS_MAX)) ctx->lut_bits_write = static_cast<uint32_t>(v);
-    }
     DeviceGuard guard(device);
     bool ok = guard.ok;
     ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
@@ -374,6 +367,10 @@ extern "C" int et_ctx_use_own_stream(et_ctx *ctx) {
     ctx->stream = ctx->own_stream;
     return ET_OK;
 }
+
+extern "C" void *et_ctx_stream(const et_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+extern "C" int et_ctx_device(const et_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 extern "C" int et_ctx_set_tile_rounds(et_ctx *ctx, uint32_t rounds) {
     if (!ctx) return ET_ERR_ARG;
@@ -479,10 +476,26 @@ int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t 
     if (reinterpret_cast<uintptr_t>(d_out) & 3) return fail(ctx, ET_ERR_ARG, "d_out must be 4-byte aligned");
     if (header_len > HEADER_STAGE - 4) return fail(ctx, ET_ERR_ARG, "header too long");
     DeviceGuard guard(ctx->device);
-    if (n == 0) {
-        if (header_len) ET_HIP(hipMemcpyAsync(d_out, header, header_len, hipMemcpyHostToDevice, ctx->stream));
+    // A shard without text, or with nothing but zero-length symbols, still owns the word its start bit lies
+    // in: that word (after the header, padded to a word, for the head shard) is written as zeros, so that a
+    // concatenation which ORs pieces together never reads what an earlier call left in d_out.
+    auto empty_shard = [&]() -> int {
+        const size_t head_words = (header_len + 3) / 4;
+        const size_t need = (header_len ? head_words : 1) * 4;
+        if (need > cap_bytes) return fail(ctx, ET_ERR_CAP, "body does not fit d_out");
+        if (header_len) {
+            std::memset(ctx->h_header, 0, head_words * 4);
+            std::memcpy(ctx->h_header, header, header_len);
+            ET_HIP(hipMemcpyAsync(d_out, ctx->h_header, head_words * 4, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            ET_HIP(hipMemsetAsync(d_out, 0, 4, ctx->stream));
+        }
         *end_bit = start_bit;
         return ET_OK;
+    };
+    if (n == 0) {
+        ET_HIP(hipStreamSynchronize(ctx->stream));  // pinned staging may still feed an earlier call
+        return empty_shard();
     }
     if (ctx->hist_text != d_text || ctx->hist_n != n)
         return fail(ctx, ET_ERR_ARG, "shard encode needs et_histogram_device on the same (d_text, n) first");
@@ -499,11 +512,7 @@ int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t 
     Geometry g = make_geometry(ctx, d_text, n);
     g.rpt = ctx->hist_rpt;
     g.n_tiles = ctx->hist_tiles;
-    if (bits == 0) {  // nothing but zero-length symbols: only the header, if any
-        if (header_len) ET_HIP(hipMemcpyAsync(d_out, ctx->h_header, (header_len + 3) & ~static_cast<size_t>(3), hipMemcpyHostToDevice, ctx->stream));
-        *end_bit = end;
-        return ET_OK;
-    }
+    if (bits == 0) return empty_shard();  // nothing but zero-length symbols
     ET_TRY(run_body(ctx, cb, g, static_cast<uint32_t *>(d_out), start_bit, header_len ? ctx->h_header : nullptr, header_len, 2, 3));
     *end_bit = end;
     if (ctx->timing) {  // hist_ms is already there (et_histogram_device); the rest when asked for
@@ -660,6 +669,28 @@ extern "C" int et_encode_fd(et_ctx *ctx, int in_fd, int out_fd, size_t *in_len, 
     return encode_through_pipe(ctx, src, static_cast<size_t>(n), out_fd >= 0 ? &dst : nullptr, ~static_cast<size_t>(0), out_len);
 }
 
+extern "C" int et_fd_to_device(et_ctx *ctx, int fd, uint64_t file_offset, size_t len, void *d_dst) {
+    if (!ctx || fd < 0 || (len && !d_dst)) return ET_ERR_ARG;
+    if (len == 0) return ET_OK;
+    DeviceGuard guard(ctx->device);
+    ET_TRY(ensure_io(ctx));
+    et_io::HostEnd src;
+    src.fd = fd;
+    src.offset = file_offset;
+    return io_status(ctx, ctx->io->upload(ctx->stream, d_dst, src, len), "reading the input");
+}
+
+extern "C" int et_device_to_fd(et_ctx *ctx, const void *d_src, size_t len, int fd, uint64_t file_offset) {
+    if (!ctx || fd < 0 || (len && !d_src)) return ET_ERR_ARG;
+    if (len == 0) return ET_OK;
+    DeviceGuard guard(ctx->device);
+    ET_TRY(ensure_io(ctx));
+    et_io::HostEnd dst;
+    dst.fd = fd;
+    dst.offset = file_offset;
+    return io_status(ctx, ctx->io->download(ctx->stream, dst, d_src, len), "writing the output");
+}
+
 // ---------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------
@@ -693,7 +724,7 @@ int prepare_decode_tables(et_ctx *ctx, const et_codebook *cb, et::DecodeTables *
     // the host can fill this one while the stream is still busy with whatever precedes this decode.
     const int turn = ctx->lut_turn ^= 1;
     ctx->h_lut = ctx->h_lut_buf[turn];
-    static const bool on_host = [] { const char *e = std::getenv("ET_DEC_TABLES_HOST"); return e && e[0] == '1'; }();  // A/B switch, and the reference the device's tables are tested against
+    static const bool on_host = [] { const char *e = std::getenv("ET_DEC_TABLES_HOST"); return e && e[0] == '1'; }();  // the host builders instead of k_build_dec_tables (they are what the device's tables are tested against)
     HostDecodeTables ht, hw;
     uint32_t *h_lut_w = ctx->h_lut + (1u << et::DEC_LUT_BITS_MAX);
     uint32_t *h_long = ctx->h_lut + (2u << et::DEC_LUT_BITS_MAX), *h_long_w = h_long + 512;
@@ -831,8 +862,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
     unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
     uint32_t *worklist = static_cast<uint32_t *>(ctx->worklist.p);
-    static const bool use_side = [] { const char *e = std::getenv("ET_DEC_SIDE"); return !(e && e[0] == '0'); }();  // A/B switch
-    const et::SideLane *side = use_side ? &ctx->side : nullptr;
+    const et::SideLane *side = &ctx->side;  // the first/last blocks' small launches run beside the large kernels (2.3 % at 1 GiB)
 
     // D1..D3.  Sweep 0 runs in and repairs inside each block; sweep 1 repairs across blocks
     // (on text ~0.4 % of the block boundaries); the scan that follows also verifies that

@@ -222,6 +222,36 @@ extern "C" int et_codebook_bits(const et_codebook *cb, const uint64_t hist[256],
     return ET_OK;
 }
 
+// encode.zig:221-247, the -d self-check, loop for loop -- including its k = 0 round, which compares the bit
+// ABOVE each code (bit `length`, index truncated to u5).
+extern "C" int et_prefix_collisions(const et_codebook *cb, uint8_t *pairs, size_t cap_pairs, size_t *n_pairs) {
+    if (!cb || !n_pairs || (cap_pairs && !pairs)) return ET_ERR_ARG;
+    size_t n = 0;
+    for (unsigned i = 0; i < 256; ++i)
+        for (unsigned j = 0; j < 256; ++j) {
+            if (cb->length[i] == 0 || cb->length[j] == 0 || i == j) continue;
+            bool is_prefix = true;
+            const unsigned shorter = cb->length[i] < cb->length[j] ? cb->length[i] : cb->length[j];
+            for (unsigned k = 0; k <= shorter; ++k) {
+                const unsigned b1 = (cb->data[i] >> ((cb->length[i] - k) & 31u)) & 1u;
+                const unsigned b2 = (cb->data[j] >> ((cb->length[j] - k) & 31u)) & 1u;
+                if (b1 != b2) {
+                    is_prefix = false;
+                    break;
+                }
+            }
+            if (is_prefix) {
+                if (n < cap_pairs) {
+                    pairs[2 * n] = static_cast<uint8_t>(i);
+                    pairs[2 * n + 1] = static_cast<uint8_t>(j);
+                }
+                ++n;
+            }
+        }
+    *n_pairs = n;
+    return ET_OK;
+}
+
 extern "C" int et_check_magic(const uint8_t first4[4], const char **why) {
     const char *reason = nullptr;
     if (!first4) return ET_ERR_ARG;

@@ -16,24 +16,10 @@ constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-st
 constexpr uint32_t SUB_BITS = 256;                             // decode: bits per lane subsequence
 constexpr uint32_t DEC_BLOCK_WORDS = BLOCK * SUB_BITS / 32;    // 8 KiB of bitstream per workgroup
 constexpr uint32_t DEC_GUARD_WORDS = 4;                        // words a lane may read past its workgroup's 8 KiB
-// How the decode kernels take their 8 KiB blocks (measured choices; -D overrides for A/B builds):
-#ifndef ET_GRID_MODE
-#define ET_GRID_MODE 1
-#endif
-#ifndef ET_SYNC_CHUNK
-#define ET_SYNC_CHUNK 1
-#endif
-#ifndef ET_SYNC_TICKET
-#define ET_SYNC_TICKET 0
-#endif
-#ifndef ET_WRITE_CHUNK
-#define ET_WRITE_CHUNK 4
-#endif
-#ifndef ET_WRITE_TICKET
-#define ET_WRITE_TICKET 1
-#endif
-constexpr uint32_t SYNC_CHUNK = ET_SYNC_CHUNK, WRITE_CHUNK = ET_WRITE_CHUNK;  // consecutive blocks per chunk
-constexpr bool SYNC_TICKET = ET_SYNC_TICKET, WRITE_TICKET = ET_WRITE_TICKET;  // chunks by ticket counter vs one per workgroup
+// How the LDS-window decode kernels take their 8 KiB blocks (measured choices): k_dec_sync one block per
+// workgroup, k_dec_write chunks of four by ticket.
+constexpr uint32_t SYNC_CHUNK = 1, WRITE_CHUNK = 4;  // consecutive blocks per chunk
+constexpr bool SYNC_TICKET = false, WRITE_TICKET = true;  // chunks by ticket counter vs one per workgroup
 constexpr uint32_t DEC_FIRST_SWEEP_TRIPS = 6;                   // local fixed-point trips before a block is declared non-synchronising
 constexpr uint32_t DEC_REPAIR_SWEEP_TRIPS = 8;                  // same cap for the two speculatively enqueued repair sweeps
 // ONE rule for "the sweeps left a final synchronisation state", applied by the host to its copy of

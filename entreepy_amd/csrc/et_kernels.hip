@@ -138,10 +138,7 @@ __device__ __forceinline__ Chunk load_chunk_in_tile(const uint8_t *__restrict__ 
 // 4 workgroups per CU (a fifth does not fit beside the others' 160 KiB exactly), so 256
 // threads meant 4 wavefronts per SIMD and a latency-bound kernel; 512 threads double the
 // loads in flight on the same LDS: 0.283 -> 0.227 ms at 1 GiB (1024 threads: 0.235).
-#ifndef ET_HIST_BLOCK
-#define ET_HIST_BLOCK 512
-#endif
-constexpr int HIST_BLOCK = ET_HIST_BLOCK;
+constexpr int HIST_BLOCK = 512;
 __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
                                                            uint32_t rounds_per_tile, uint32_t n_tiles,
                                                            uint32_t *__restrict__ tile_hist,
@@ -293,13 +290,18 @@ __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__rest
     if (i < n) {
         const unsigned long long v = out[i] + prefix;
         out[i] = v;
-        if (zero_words && ((v >> 5) != seam || i == 0)) zero_words[v >> 5] = 0;
+        // (K4 merges with atomicOr into the word a tile ENDS in when that end is not word-aligned: the next
+        // tile's first word, zeroed here by that tile's thread, or the stream's last word, below; a tile that
+        // starts on a word boundary owes nobody a zeroed word -- and for trailing zero-bit tiles at a
+        // word-aligned end that word lies past the shard.  The shard's very first word is always zeroed: a
+        // short shard may end in it.)
+        if (zero_words && (i == 0 || ((v & 31) && (v >> 5) != seam))) zero_words[v >> 5] = 0;
     }
     if (g == gridDim.x - 1 && tid == 0) {
         const unsigned long long total = prefix + group_sum[g];
         out[n] = total;
         if (total_copy) *total_copy = total;  // next to the sweep flags
-        if (zero_words && (total >> 5) != seam) zero_words[total >> 5] = 0;
+        if (zero_words && (total >> 5) != seam && (total & 31)) zero_words[total >> 5] = 0;  // (no open word at a word-aligned end)
         if (report_dst) {
             // the decode's report to the host, stored straight into pinned host memory (no copy
             // command between this kernel and the write kernel behind it): words 0..11 = the
@@ -1150,10 +1152,6 @@ __device__ __forceinline__ uint32_t long_code_flat(const uint16_t *sub, const ui
     return hit;
 }
 
-#ifndef ET_RW_WARM_WORDS
-#define ET_RW_WARM_WORDS 4
-#endif
-constexpr int RW_WARM_WORDS = ET_RW_WARM_WORDS;  // run-in of k_dec_sync_reg, in words (A/B knob; the loads stay)
 constexpr int RW_WORDS = 13;  // W[j] = stream word 8 * sub - 4 + j (host order): 4 run-in words, 8 own, 1 beyond
 
 __host__ __device__ __forceinline__ uint32_t step_table_words(const DecodeTables &tb) {
@@ -1161,9 +1159,6 @@ __host__ __device__ __forceinline__ uint32_t step_table_words(const DecodeTables
 }
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
-#ifndef ET_ASM_WALK
-#define ET_ASM_WALK 1
-#endif
 
 // Kernel-argument form of a step table (DecodeTables::steps ...): the table in global
 // memory, its size in words (both levels, multiple of 4), and the device copy of the
@@ -1187,10 +1182,7 @@ struct StepWalk {
     uint32_t idx_shift, step_bits, sub_bits, multi_floor;
 };
 
-#ifndef ET_SLOW_INLINE
-#define ET_SLOW_INLINE __attribute__((noinline))
-#endif
-__device__ ET_SLOW_INLINE uint32_t decode_one_slow_p(const DecodeTables *tb, uint32_t window) {
+__device__ __attribute__((noinline)) uint32_t decode_one_slow_p(const DecodeTables *tb, uint32_t window) {
     const uint32_t bits = tb->lut_bits | (tb->sub_bits << 8);
     const uint32_t e = tb->lut[window >> (32 - tb->lut_bits)];
     if ((e >> LUT_N_SHIFT) & 3u) return (static_cast<uint32_t>(tb->sym_len[e & 0xffu]) << 8) | (e & 0xffu);
@@ -1221,7 +1213,6 @@ __device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32
 // here v_cmp_le_u16 reads the low half directly and lanes that leave the word are dropped
 // from exec.  5 VALU + 1 LDS + 2 SALU per step.  floor_ = lowest G still in the word (an
 // inline constant or an SGPR).
-#if ET_ASM_WALK
 #define ET_SW_LOOP(hi_, lo_, floor_)                                                   \
     {                                                                                  \
         uint32_t t_;                                                                   \
@@ -1247,9 +1238,6 @@ __device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32
             : [hi] "v"(hi_), [lo] "v"(lo_), [sh] "s"(idx_shift), [base] "v"(steps_lds), [fl] "s"(floor_) \
             : "vcc", "scc");                                                           \
     }
-#else
-#define ET_SW_LOOP(hi_, lo_, floor_) while (ET_F >= (floor_)) ET_SW_STEP(hi_, lo_)
-#endif
 // the code at X is longer than the index (`e` is its escape entry): second-level table, else the slow way
 #define ET_SW_SLOW(hi_, lo_)                                                                                           \
     {                                                                                                                  \
@@ -1288,10 +1276,10 @@ __device__ __forceinline__ SubResult walk_steps(const StepWalk &sw, const uint32
     }
 
     if (WARM) {
-        X = 64;  // first bit of the run-in's first word
-        if (RW_WARM_WORDS >= 4) ET_SW_WORD(0u, W[0])
-        if (RW_WARM_WORDS >= 3) ET_SW_WORD(W[0], W[1])
-        if (RW_WARM_WORDS >= 2) ET_SW_WORD(W[1], W[2])
+        X = 64;  // first bit of the run-in's first word (128 bits: 96 or 64 mean more re-walks, 0.61 / 0.64 vs 0.59 ms)
+        ET_SW_WORD(0u, W[0])
+        ET_SW_WORD(W[0], W[1])
+        ET_SW_WORD(W[1], W[2])
         ET_SW_WORD(W[2], W[3])
         ET_SW_LAST_WORD(W[3], W[4])
         X &= 0xffffu;  // nothing counted so far
@@ -1375,11 +1363,8 @@ __device__ __forceinline__ SubResult rewalk_steps(const StepWalk &sw, const uint
 // beyond.  The state arrays keep their 256-bit granularity (the lane produces both
 // entries), so the repair sweeps, the scan and D3 are unchanged.
 // (checkpointed re-walks as in rewalk_steps cost this kernel a wavefront of occupancy for
-// the eight extra registers: 0.40 vs 0.39 ms -> off; a re-walked lane walks its first
+// the eight extra registers: 0.40 vs 0.39 ms -> none here; a re-walked lane walks its first
 // subsequence again in full)
-#ifndef ET_REG2_CK
-#define ET_REG2_CK 0
-#endif
 constexpr int RW2_WORDS = 21;
 struct Sub2Result {
     uint32_t start_rel, exit1, count1, exit2, count2;
@@ -1395,27 +1380,8 @@ struct Sub2Result {
     ET_SW_WORD(W[(B_) + 9], W[(B_) + 10])   \
     ET_SW_WORD(W[(B_) + 10], W[(B_) + 11])  \
     ET_SW_LAST_WORD(W[(B_) + 11], W[(B_) + 12])
-#define ET_SW_HALF(B_, ck_)                 \
-    ET_SW_WORD(W[(B_) + 3], W[(B_) + 4])    \
-    ck_[0] = X;                             \
-    ET_SW_WORD(W[(B_) + 4], W[(B_) + 5])    \
-    ck_[1] = X;                             \
-    ET_SW_WORD(W[(B_) + 5], W[(B_) + 6])    \
-    ck_[2] = X;                             \
-    ET_SW_WORD(W[(B_) + 6], W[(B_) + 7])    \
-    ck_[3] = X;                             \
-    ET_SW_WORD(W[(B_) + 7], W[(B_) + 8])    \
-    ck_[4] = X;                             \
-    ET_SW_WORD(W[(B_) + 8], W[(B_) + 9])    \
-    ck_[5] = X;                             \
-    ET_SW_WORD(W[(B_) + 9], W[(B_) + 10])   \
-    ck_[6] = X;                             \
-    ET_SW_WORD(W[(B_) + 10], W[(B_) + 11])  \
-    ck_[7] = X;                             \
-    ET_SW_LAST_WORD(W[(B_) + 11], W[(B_) + 12])
-
 template <bool WARM>
-__device__ __forceinline__ Sub2Result walk_steps2(const StepWalk &sw, const uint32_t (&W)[RW2_WORDS], uint32_t start_rel, uint32_t (&ck1)[8]) {
+__device__ __forceinline__ Sub2Result walk_steps2(const StepWalk &sw, const uint32_t (&W)[RW2_WORDS], uint32_t start_rel) {
     const uint32_t *steps = sw.steps;
     const uint32_t idx_shift = sw.idx_shift;
     const uint32_t steps_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)steps));
@@ -1435,11 +1401,7 @@ __device__ __forceinline__ Sub2Result walk_steps2(const StepWalk &sw, const uint
     } else {
         X = 64 - start_rel;
     }
-#if ET_REG2_CK
-    ET_SW_HALF(0, ck1)
-#else
     ET_SW_HALF_PLAIN(0)
-#endif
     res.exit1 = 64 - (X & 0xffffu);
     res.count1 = (X >> 16) & 0xfffu;
     X &= 0xffffu;  // the second subsequence starts where the first one's last codeword ended, and counts from zero
@@ -1449,49 +1411,16 @@ __device__ __forceinline__ Sub2Result walk_steps2(const StepWalk &sw, const uint
     return res;
 }
 
-// rewalk_steps for a 512-bit lane: `r` holds the previous walk's results and is updated.
-// Once the new walk merges with the old one the rest -- also the whole second
-// subsequence -- stays as it is.
-__device__ __forceinline__ void rewalk_steps2(const StepWalk &sw, const uint32_t (&W)[RW2_WORDS], uint32_t start_rel, uint32_t (&ck1)[8],
-                                              Sub2Result &r) {
+// The re-walk of a 512-bit lane from a corrected start: `r` holds the previous walk's results and is
+// updated.  If the first subsequence ends where it ended before, the second one stays as it is.
+__device__ __forceinline__ void rewalk_steps2(const StepWalk &sw, const uint32_t (&W)[RW2_WORDS], uint32_t start_rel, Sub2Result &r) {
     const uint32_t *steps = sw.steps;
     const uint32_t idx_shift = sw.idx_shift;
     const uint32_t steps_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)steps));
     (void)steps_lds;
     uint32_t X = 64 - start_rel, e = 0;
     r.start_rel = start_rel;
-    bool merged = false;
-    uint32_t shift = 0;
-    (void)shift;
-#if !ET_REG2_CK
-#define ET_RW2_CHECK(ck_, c_, hi_, lo_, count_) ET_SW_WORD(hi_, lo_)
-#else
-#define ET_RW2_CHECK(ck_, c_, hi_, lo_, count_)                                              \
-    if (!merged) {                                                                           \
-        ET_SW_WORD(hi_, lo_)                                                                 \
-        if (static_cast<uint16_t>(X) == static_cast<uint16_t>(ck_[c_])) {                    \
-            merged = true;                                                                   \
-            const uint32_t nc_ = (count_ + (X >> 16) - (ck_[c_] >> 16)) & 0xfffu;            \
-            shift = (nc_ - count_) << 16;                                                    \
-            count_ = nc_;                                                                    \
-        }                                                                                    \
-        ck_[c_] = X;                                                                         \
-    } else {                                                                                 \
-        ck_[c_] += shift;                                                                    \
-    }
-#endif
-#define ET_RW2_HALF(B_, ck_, count_)                                 \
-    ET_RW2_CHECK(ck_, 0, W[(B_) + 3], W[(B_) + 4], count_)           \
-    ET_RW2_CHECK(ck_, 1, W[(B_) + 4], W[(B_) + 5], count_)           \
-    ET_RW2_CHECK(ck_, 2, W[(B_) + 5], W[(B_) + 6], count_)           \
-    ET_RW2_CHECK(ck_, 3, W[(B_) + 6], W[(B_) + 7], count_)           \
-    ET_RW2_CHECK(ck_, 4, W[(B_) + 7], W[(B_) + 8], count_)           \
-    ET_RW2_CHECK(ck_, 5, W[(B_) + 8], W[(B_) + 9], count_)           \
-    ET_RW2_CHECK(ck_, 6, W[(B_) + 9], W[(B_) + 10], count_)          \
-    ET_RW2_CHECK(ck_, 7, W[(B_) + 10], W[(B_) + 11], count_)
-    ET_RW2_HALF(0, ck1, r.count1)
-    if (merged) return;
-    ET_SW_LAST_WORD(W[11], W[12])
+    ET_SW_HALF_PLAIN(0)
     const uint32_t new_exit1 = 64 - (X & 0xffffu);
     r.count1 = (X >> 16) & 0xfffu;
     if (new_exit1 == r.exit1) return;  // the second subsequence starts where it started before
@@ -1500,10 +1429,7 @@ __device__ __forceinline__ void rewalk_steps2(const StepWalk &sw, const uint32_t
     ET_SW_HALF_PLAIN(8)
     r.exit2 = 64 - (X & 0xffffu);
     r.count2 = (X >> 16) & 0xfffu;
-#undef ET_RW2_HALF
-#undef ET_RW2_CHECK
 }
-#undef ET_SW_HALF
 #undef ET_SW_HALF_PLAIN
 #undef ET_SW_LAST_WORD
 #undef ET_SW_WORD
@@ -1526,22 +1452,7 @@ __device__ __forceinline__ void load_window(uint32_t (&W)[RW_WORDS], const uint3
 // SGPRs, which caps it at 7 wavefronts per SIMD; asked for 8 the compiler parks ~24 of them in
 // VGPR lanes and the kernel is 11 % faster (0.52 -> 0.46 ms); 9 is out of reach.  k_dec_write_reg
 // is held at 6 workgroups per CU by its LDS, so the same request changes nothing there.
-#ifndef ET_SYNC_WAVES
-#define ET_SYNC_WAVES 8
-#endif
-#ifndef ET_WRITE_WAVES
-#define ET_WRITE_WAVES 0
-#endif
-#if ET_SYNC_WAVES
-#define ET_SYNC_ATTR __attribute__((amdgpu_waves_per_eu(ET_SYNC_WAVES, 10)))
-#else
-#define ET_SYNC_ATTR
-#endif
-#if ET_WRITE_WAVES
-#define ET_WRITE_ATTR __attribute__((amdgpu_waves_per_eu(ET_WRITE_WAVES, 10)))
-#else
-#define ET_WRITE_ATTR
-#endif
+#define ET_SYNC_ATTR __attribute__((amdgpu_waves_per_eu(8, 10)))
 template <bool FIRST, bool TICKET>
 __global__ __launch_bounds__(BLOCK) ET_SYNC_ATTR void k_dec_sync_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                         StepTableArgs ta, uint32_t *__restrict__ sub_state,
@@ -1671,13 +1582,13 @@ __global__ __launch_bounds__(BLOCK) ET_SYNC_ATTR void k_dec_sync_reg2(const uint
         if (sb >= n_super) break;
         if (!super_interior(sb, n_bytes, n_blocks)) continue;
         const uint64_t q = sb * BLOCK + tid;  // 512-bit lane index = subsequences 2q, 2q + 1
-        uint32_t W[RW2_WORDS], ck1[8];
+        uint32_t W[RW2_WORDS];
         {
             const uint32_t *src = words + q * (2 * SUB_BITS / 32) - 4;
 #pragma unroll
             for (int j = 0; j < RW2_WORDS; ++j) W[j] = __builtin_bswap32(src[j]);
         }
-        Sub2Result r = walk_steps2<true>(sw, W, 0, ck1);
+        Sub2Result r = walk_steps2<true>(sw, W, 0);
         uint32_t start = r.start_rel;
         for (uint32_t trip = 1;; ++trip) {
             exits[tid] = r.exit2;
@@ -1692,7 +1603,7 @@ __global__ __launch_bounds__(BLOCK) ET_SYNC_ATTR void k_dec_sync_reg2(const uint
                 break;
             }
             if (need) {
-                rewalk_steps2(sw, W, cand, ck1, r);
+                rewalk_steps2(sw, W, cand, r);
                 start = cand;
             }
         }
@@ -1882,7 +1793,7 @@ __device__ __forceinline__ void walk_write(const StepWalk &sw, const uint8_t *sy
 }
 
 // D3 for interior blocks (tickets of WRITE_CHUNK blocks, as k_dec_write).
-__global__ __launch_bounds__(BLOCK) ET_WRITE_ATTR void k_dec_write_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+__global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                          StepTableArgs ta, const uint8_t *__restrict__ sym_len_g, const uint32_t *__restrict__ sub_state,
                                                          const unsigned long long *__restrict__ blk_off, uint64_t n_symbols,
                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ ticket,
@@ -2046,12 +1957,9 @@ static inline size_t decode_smem_bytes(const DecodeTables &tb, bool with_stage, 
     return ((with_stream ? DEC_SDATA_WORDS : 0) + (1u << tb.lut_bits) + sub_w + 64 + (with_exits ? BLOCK : 0) + 8) * sizeof(uint32_t) + (with_stage ? DEC_STAGE_BYTES + 16 : 0);
 }
 
-// ET_DEC_REG=0 keeps every block on the LDS-window kernels (A/B switch; default: interior
-// blocks take the register-window kernels).
-static bool use_reg_kernels(uint32_t n_blocks) {
-    static const bool on = [] { const char *e = getenv("ET_DEC_REG"); return !(e && e[0] == '0'); }();
-    return on && n_blocks > 3;  // (fewer: nothing but special blocks)
-}
+// Interior blocks take the register-window kernels; the LDS-window kernels keep the stream's first
+// and last blocks (and streams of nothing else).
+static bool use_reg_kernels(uint32_t n_blocks) { return n_blocks > 3; }
 
 // A launch that carries its own timing events (hipExtLaunchKernelGGL: the dispatch's completion
 // signal records begin and end, no marker packets in the stream -- ten hipEventRecord markers per
@@ -2062,27 +1970,40 @@ static bool use_reg_kernels(uint32_t n_blocks) {
         else hipLaunchKernelGGL(kernel_, grid_, block_, smem_, stream_, __VA_ARGS__);                                             \
     } while (0)
 
-// Grid of the tile-striding encode kernels: the workgroups the device holds at once
-// (occupancy query; both kernels use < 64 SGPRs, where the query is exact), so that
-// every workgroup gets within one tile of the same share.  ET_GRID_MODE=0: fixed 2048.
-template <typename K>
-static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
-    uint32_t g = MAX_GRID;
-#if ET_GRID_MODE
-    static thread_local int seen_dev = -1, cus = 256, per_cu = 0;  // (remembered: on the launch path)
+// Workgroups of `kernel` a CU holds at once (occupancy query), remembered per (kernel, device, LDS size):
+// the query sits on the launch path, and kernels that share a signature (the k_encode_tiles<RING> variants,
+// k_dec_sync<first/later>, the k_dec_sync_reg variants) are different entries.
+static int resident_per_cu(const void *kernel, size_t smem, int *cus_out) {
+    struct Entry {
+        const void *kernel;
+        size_t smem;
+        int dev, cus, per_cu;
+    };
+    static thread_local Entry cache[24];
+    static thread_local int n_cached = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev != seen_dev) {
-        cus = 256;
-        per_cu = 0;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess) per_cu = 0;
-        seen_dev = dev;
-    }
-    if (per_cu >= 1)
-        g = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
+    for (int i = 0; i < n_cached; ++i)
+        if (cache[i].kernel == kernel && cache[i].smem == smem && cache[i].dev == dev) {
+            *cus_out = cache[i].cus;
+            return cache[i].per_cu;
+        }
+    int cus = 256, per_cu = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, smem) != hipSuccess) per_cu = 0;
+    if (n_cached < 24) cache[n_cached++] = Entry{kernel, smem, dev, cus, per_cu};
+    *cus_out = cus;
+    return per_cu;
+}
+
+// Grid of the tile-striding encode kernels: the workgroups the device holds at once (both kernels use
+// < 64 SGPRs, where the query is exact), so that every workgroup gets within one tile of the same share.
+template <typename K>
+static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
+    int cus = 256;
+    const int per_cu = resident_per_cu(reinterpret_cast<const void *>(kernel), 0, &cus);
+    uint32_t g = per_cu >= 1 ? static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu) : MAX_GRID;
     if (g > MAX_GRID) g = MAX_GRID;
-#endif
     return n_tiles < g ? n_tiles : g;
 }
 
@@ -2090,12 +2011,10 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, KernelEvents ev) {
     // 4 workgroups per CU are resident (LDS): 1024 = one full batch (0.227 ms at 1 GiB; 2048 = two
     // batches 0.231; 1280 or 1536 = a full and a partial batch, 0.32-0.36)
-    static const uint32_t want = [] { const char *e = getenv("ET_HIST_GRID"); return e && atoi(e) > 0 && atoi(e) <= static_cast<int>(MAX_GRID) ? static_cast<uint32_t>(atoi(e)) : 1024u; }();
-    const uint32_t grid = n_tiles < want ? n_tiles : want;
+    const uint32_t grid = n_tiles < 1024u ? n_tiles : 1024u;
     (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
     ET_LAUNCH_TIMED(k_hist_tiles, dim3(grid), dim3(HIST_BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
-    static const uint32_t rwant = [] { const char *e = getenv("ET_HIST_RGRID"); return e && atoi(e) > 0 ? static_cast<uint32_t>(atoi(e)) : 128u; }();  // workgroups of the reduction; measured 16 / 32 / 64 / 128 / 512: 20.8 / 11.1 / 5.7 / 5.5 / 12.9 us (512: 131 K atomics on 256 addresses)
-    const uint32_t rgrid = grid < rwant ? grid : rwant;
+    const uint32_t rgrid = grid < 128u ? grid : 128u;  // workgroups of the reduction; measured 16 / 32 / 64 / 128 / 512: 20.8 / 11.1 / 5.7 / 5.5 / 12.9 us (512: 131 K atomics on 256 addresses)
     hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
 }
 
@@ -2259,19 +2178,9 @@ void launch_build_dec_tables(hipStream_t stream, const TablePlan *d_plan, uint32
 template <typename K>
 static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticketed) {
     if (!ticketed) return n_chunks;
-    // (the queries are remembered per kernel and LDS size: they sit on the launch path)
-    static thread_local size_t seen_smem = ~static_cast<size_t>(0);
-    static thread_local int seen_dev = -1, cus = 256, per_cu = 1;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev != seen_dev || smem != seen_smem) {
-        cus = 256;
-        per_cu = 1;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, smem) != hipSuccess || per_cu < 1) per_cu = 1;
-        seen_dev = dev;
-        seen_smem = smem;
-    }
+    int cus = 256;
+    int per_cu = resident_per_cu(reinterpret_cast<const void *>(kernel), smem, &cus);
+    if (per_cu < 1) per_cu = 1;
     const uint32_t g = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
     return n_chunks < g ? (n_chunks ? n_chunks : 1) : g;
 }
@@ -2305,27 +2214,22 @@ void launch_dec_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
     const size_t smem = decode_smem_bytes(tb, false);
     if (use_reg_kernels(n_blocks)) {
         const size_t smem_reg = (step_table_words(tb) + BLOCK + 8) * sizeof(uint32_t);
-        static const uint32_t chunk = [] { const char *e = getenv("ET_SYNC_REG_TICKET"); return e ? static_cast<uint32_t>(atoi(e)) : 4u; }();  // blocks per ticket (0: one workgroup per block); measured 0/4/8/16
-        const bool ticketed = chunk > 0;
-        static const bool lanes512 = [] { const char *e = getenv("ET_SYNC_LANE512"); return !(e && e[0] == '0'); }();  // A/B switch
-        if (iter == 0 && ticketed && lanes512 && n_blocks >= 16) {
+        constexpr uint32_t chunk = 4;  // blocks per ticket; measured 1 / 4 / 8 / 16
+        if (iter == 0 && n_blocks >= 16) {
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-            static const uint32_t chunk2 = [] { const char *e = getenv("ET_SYNC_REG2_TICKET"); return e && atoi(e) > 0 ? static_cast<uint32_t>(atoi(e)) : 4u; }();  // superblocks per ticket; measured 1 / 2 / 4 / 8 / 16: 0.54 / 0.37 / 0.35 / 0.37 / 0.44 ms
+            constexpr uint32_t chunk2 = 4;  // superblocks per ticket; measured 1 / 2 / 4 / 8 / 16: 0.54 / 0.37 / 0.35 / 0.37 / 0.44 ms
             fork_mark(side, stream);
             ET_LAUNCH_TIMED(k_dec_sync_reg2, dim3(decode_grid(k_dec_sync_reg2, smem_reg, (n_blocks / 2 + chunk2 - 1) / chunk2, true)), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk2);
             const hipStream_t special = fork_special(side, stream);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(8), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY | DEC_SPECIAL_SUPER);
             join_special(side, stream);
-        } else if (iter == 0 && ticketed) {
+        } else if (iter == 0) {
             if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
             fork_mark(side, stream);
             ET_LAUNCH_TIMED((k_dec_sync_reg<true, true>), dim3(decode_grid(k_dec_sync_reg<true, true>, smem_reg, (n_blocks + chunk - 1) / chunk, true)), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
             const hipStream_t special = fork_special(side, stream);
             hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
             join_special(side, stream);
-        } else if (iter == 0) {
-            ET_LAUNCH_TIMED((k_dec_sync_reg<true, false>), dim3(n_blocks), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), sub_state, blk_exit, blk_count, changed, ticket, max_trips, chunk, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
-            hipLaunchKernelGGL(k_dec_sync<true>, dim3(3), dim3(BLOCK), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, tb, sub_state, blk_exit, blk_count, changed, ticket, max_trips, flags | DEC_SPECIAL_ONLY);
         } else {
             if (worklist) {  // n_work zeroed by the caller
                 hipLaunchKernelGGL(k_dec_check, dim3((n_blocks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, sub_state, blk_exit, n_blocks, worklist, n_work);

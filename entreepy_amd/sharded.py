@@ -1,22 +1,30 @@
 """One stream sharded by contiguous chunk across the GPUs of a node (one process per GPU).
 
+The sequencing lives behind the C ABI (csrc/et_sharded.cpp: et_encode_sharded,
+et_shard_merge_seams, et_shard_write_fd / _place / _gather, et_decode_sharded); this module is
+its torch.distributed host: it supplies the exchange -- RCCL over xGMI for backend "nccl" (the
+library opens its own communicator from an id broadcast once), an all-gather over the process
+group otherwise (gloo) -- and keeps the layout dicts bench.py and the tests use.
+
 Encode has exactly one exchange step: the byte histogram.  Every rank
   1. histograms its chunk on its GPU (K1),
-  2. all-gathers the 256 x u64 local histograms (RCCL over xGMI; 2 KiB per rank --
-     latency-bound, one collective).  The sum is the global histogram the reference
-     computes in encode.zig:43-47; the individual rows give every shard's body bit
-     count as sum(hist_r * length) with no further data pass or collective,
-  3. builds the same code table from the same global histogram (deterministic host
-     code, et_build_codebook), so no table broadcast is needed,
-  4. packs its chunk at its global bit offset (K2 + K4).  Rank r's piece covers file
-     words [S_r // 32, ceil(S_{r+1} / 32)) and holds zeros for the bits of a shared
-     boundary word that belong to a neighbour.
-The file then exists as per-rank pieces resident in HBM; the bit-offset-adjusted
-concatenation (`gather_file`: pieces OR-ed into place on rank 0) is used by tests and
-the CLI and is not part of the timed step (a host `pwrite` per shard needs no gather).
+  2. all-gathers the 256 x u64 local histograms (2 KiB per rank -- latency-bound, one
+     collective).  The sum is the global histogram the reference computes in
+     encode.zig:43-47; the individual rows give every shard's body bit count as
+     sum(hist_r * length) with no further data pass or collective,
+  3. builds the same code table from the same global histogram (deterministic host code,
+     et_plan_shards), so no table broadcast is needed,
+  4. packs its chunk at its global bit offset (K2 + K4).  Rank r's piece covers file words
+     [S_r // 32, ceil(S_{r+1} / 32)) and holds zeros for the bits of a shared boundary word
+     that belong to a neighbour.
+The bit-offset-adjusted concatenation (encode.zig:319 writes ONE image): the owner of a shared
+word -- the first shard in it -- receives its successors' bits (merge_seams: one 8-byte
+exchange), after which every rank's owned words are a disjoint range of the image and go to a
+file (pwrite per shard) or to rank 0's image over xGMI.
 
-The collectives go through torch.distributed (backend "nccl" == RCCL on ROCm; "gloo"
-in the CPU tests, where a fake compute backend stands in for the GPU).
+A context that is not an entreepy_amd.Context (the CPU tests' oracle-backed stand-in for the
+GPU) takes the same steps in Python; the word arithmetic is the library's either way
+(et_plan_shards, et_shard_words, et_seam_word).
 """
 import time
 
@@ -24,7 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .codec import Codebook
+from .codec import Codebook, Context, Group, seam_word, shard_words
 
 
 def plan_shards(hists):
@@ -50,17 +58,13 @@ def plan_shards(hists):
 
 def piece_words(starts, r):
     """File words [lo, hi) held by rank r's local buffer."""
-    lo = 0 if r == 0 else starts[r] // 32
-    hi = (starts[r + 1] + 31) // 32
-    return lo, max(hi, lo)
+    return shard_words(starts, len(starts) - 1, r)[:2]
 
 
 def owned_words(starts, r):
     """File words rank r contributes to the concatenation: a word shared by several
     ranks belongs to the first of them."""
-    lo = 0 if r == 0 else (starts[r] + 31) // 32
-    hi = (starts[r + 1] + 31) // 32
-    return lo, max(hi, lo)
+    return shard_words(starts, len(starts) - 1, r)[2:]
 
 
 def cut_blocks(stream_bytes):
@@ -87,7 +91,25 @@ class ShardedCodec:
         self.all_hists = torch.zeros(self.world * 256, dtype=torch.int64, device=self.coll_device)
         # the gathered counts come to the host through a pinned buffer (a pageable .cpu() costs ~10 us more per step)
         self.h_hists = torch.zeros(self.world * 256, dtype=torch.int64).pin_memory() if self.coll_device.type == "cuda" else None
-        self._hdr_len = {}
+        # A real Context sequences through the library (et_sharded.cpp); the exchange is RCCL of the
+        # library's own when the process group is RCCL, else an all-gather over the process group.
+        self.lib_group = None
+        if isinstance(ctx, Context):
+            ctx.use_torch_stream()  # the tensors handed in are produced (and consumed) on torch's current stream
+        if isinstance(ctx, Context) and group is not None:
+            if dist.get_backend(group) == "nccl":
+                ident = [Group.rccl_unique_id() if self.rank == 0 else None]
+                dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0), group=group)
+                self.lib_group = Group(ctx, self.rank, self.world, rccl_id=ident[0])
+            else:
+                self.lib_group = Group(ctx, self.rank, self.world, allgather=self._gather_bytes)
+
+    def _gather_bytes(self, mine):
+        """The exchange callback over the process group: bytes of this rank -> bytes of all, rank order."""
+        send = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        recv = torch.empty(self.world * send.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv.numpy().tobytes()
 
     # ------------------------------------------------------------------ encode
     def encode_shard(self, text, enc, timings=True):
@@ -100,12 +122,17 @@ class ShardedCodec:
         ctx = self.ctx
         if self.group is None:
             et_len = ctx.encode_device(text, enc)
-            hdr = self._hdr_len.get(et_len)
-            if hdr is None:
-                cbk, _, off = _parse_device_header(enc, et_len)
-                hdr = self._hdr_len[et_len] = off + 4
+            # header length from the call's own code table (9 bytes + the bit-packed dictionary, encode.zig:259-299)
+            hdr = len(ctx.last_codebook().header(n))
             return {"world": 1, "single": True, "n": n, "et_len": et_len, "header_len": hdr, "body_bytes": et_len - hdr,
                     "timings": self.single_encode_timings() if timings else None}
+        if self.lib_group is not None:
+            i = self.lib_group.encode_sharded(text, enc)
+            self._host_timings = {"enc_host": i["plan_ms"], "exchange": i["exchange_ms"]}
+            return {"world": self.world, "single": False, "n": n, "codebook": self.lib_group.codebook(), "header_len": i["header_len"],
+                    "starts": self.lib_group.start_bits(), "local_start_bit": i["local_start_bit"],
+                    "end_bit": i["local_start_bit"] + (i["end_bit"] - i["start_bit"]), "body_bytes": (i["end_bit"] - i["start_bit"] + 7) // 8,
+                    "info": i, "timings": self.encode_timings() if timings else None}
 
         ctx.histogram_device(text, self.hist)
         t_x0 = time.perf_counter()
@@ -181,6 +208,8 @@ class ShardedCodec:
         Expected rounds: 1 (a run-in is right 99.6 % of the time on text)."""
         from .codec import parse_header
 
+        if self.lib_group is not None:
+            return self.lib_group.decode_sharded(compressed, dec)
         world, r = self.world, self.rank
         head = compressed[: min(compressed.numel(), 8192)].cpu().numpy()
         cb, n_symbols, body_off = parse_header(head)
@@ -241,25 +270,50 @@ class ShardedCodec:
         return written, first
 
     # ------------------------------------------------------------------ concat
+    def merge_seams(self, enc, layout):
+        """The owner of a word several shards share receives the later shards' bits (in place, in enc)."""
+        if layout["single"]:
+            return
+        if self.lib_group is not None:
+            self.lib_group.merge_seams(enc)
+            return
+        starts, r = layout["starts"], self.rank
+        lo, hi = piece_words(starts, r)
+        holds = starts[r + 1] > starts[r] or r == 0
+        words = enc[: (hi - lo) * 4].cpu().numpy().view(np.uint32) if holds and hi > lo else np.zeros(0, dtype=np.uint32)
+        mine = torch.tensor([int(words[0]), int(words[-1])] if words.size else [0, 0], dtype=torch.int64)
+        both = torch.zeros(2 * self.world, dtype=torch.int64)
+        dist.all_gather_into_tensor(both, mine, group=self.group)
+        merged = seam_word(starts, self.world, r, both.numpy().astype(np.uint32))
+        if merged is not None:
+            enc[(hi - lo - 1) * 4 : (hi - lo) * 4] = torch.from_numpy(np.array([merged], dtype=np.uint32).view(np.uint8).copy()).to(enc.device)
+
     def gather_file(self, enc, layout):
-        """Bit-offset-adjusted concatenation on rank 0 -> bytes (None elsewhere)."""
+        """Bit-offset-adjusted concatenation on rank 0 -> bytes (None elsewhere): seams merged, then
+        every rank's owned words into place -- over xGMI (RCCL send/recv) into an image on rank 0's
+        GPU, or, without RCCL, as one tensor gather over the process group."""
         if layout["single"]:
             return enc[: layout["et_len"]].cpu().numpy().tobytes()
         starts, r = layout["starts"], self.rank
-        lo, hi = piece_words(starts, r)
-        mine = enc[: (hi - lo) * 4].cpu().numpy().tobytes()
-        pieces = [None] * self.world
-        dist.all_gather_object(pieces, mine, group=self.group)
+        file_bytes = (starts[-1] + 7) // 8
+        self.merge_seams(enc, layout)
+        if self.lib_group is not None and dist.get_backend(self.group) == "nccl":
+            image = torch.zeros((file_bytes + 3) // 4 * 4, dtype=torch.uint8, device=enc.device) if r == 0 else None
+            self.lib_group.gather(enc, image, 0)
+            return image[:file_bytes].cpu().numpy().tobytes() if r == 0 else None
+        plo, _, olo, ohi = shard_words(starts, self.world, r)
+        spans = [shard_words(starts, self.world, q)[2:] for q in range(self.world)]
+        longest = max(1, max(h - l for l, h in spans) * 4)
+        mine = torch.zeros(longest, dtype=torch.uint8)
+        mine[: (ohi - olo) * 4] = enc[(olo - plo) * 4 : (ohi - plo) * 4].cpu()
+        pieces = [torch.zeros(longest, dtype=torch.uint8) for _ in range(self.world)] if r == 0 else None
+        dist.gather(mine, pieces, dst=dist.get_global_rank(self.group, 0), group=self.group)
         if r != 0:
             return None
-        # A word two (or more) neighbouring pieces share holds disjoint bits of each and
-        # zeros elsewhere: OR the pieces into place.
         image = np.zeros(((starts[-1] + 31) // 32) * 4, dtype=np.uint8)
-        for q, piece in enumerate(pieces):
-            qlo, _ = piece_words(starts, q)
-            a = np.frombuffer(piece, dtype=np.uint8)
-            image[qlo * 4 : qlo * 4 + a.size] |= a
-        return image[: (starts[-1] + 7) // 8].tobytes()
+        for (l, h), piece in zip(spans, pieces):
+            image[l * 4 : h * 4] = piece.numpy()[: (h - l) * 4]
+        return image[:file_bytes].tobytes()
 
 
 def _parse_device_header(enc, et_len):

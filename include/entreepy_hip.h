@@ -35,7 +35,8 @@ typedef enum et_status {
     ET_ERR_HIP = 5,         /* HIP runtime failure; et_last_error() has the text */
     ET_ERR_ARG = 6,         /* null/misaligned/out-of-range argument */
     ET_ERR_UNSUPPORTED = 7, /* stream needs a feature outside the decoder's domain (code length > 32) */
-    ET_ERR_IO = 8           /* read/write on a file descriptor failed (et_encode_fd / et_decode_fd) */
+    ET_ERR_IO = 8,          /* read/write on a file descriptor failed (et_encode_fd / et_decode_fd) */
+    ET_ERR_RCCL = 9         /* the exchange between the GPUs of a group failed (RCCL error, or the callback's) */
 } et_status;
 
 /* The reference's `dictionary: [256]Code` (encode.zig:141-146) plus what its -d dump
@@ -80,6 +81,9 @@ void et_ctx_destroy(et_ctx *ctx);
 int et_ctx_set_stream(et_ctx *ctx, void *hip_stream);
 /* Back to the non-blocking stream the ctx created for itself. */
 int et_ctx_use_own_stream(et_ctx *ctx);
+/* The hipStream_t the ctx's calls are enqueued on, and its HIP device ordinal. */
+void *et_ctx_stream(const et_ctx *ctx);
+int et_ctx_device(const et_ctx *ctx);
 /* Pre-size workspaces for inputs of up to max_text_bytes so that no allocation
  * happens inside a timed call. */
 int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes);
@@ -131,6 +135,12 @@ int et_decode_fd(et_ctx *ctx, int in_fd, size_t in_skip, int out_fd, size_t *in_
 /* Code table of the ctx's most recent et_encode / et_encode_device (for the -d dump,
  * encode.zig:204-212, which the reference prints from inside encode()). */
 int et_last_codebook(const et_ctx *ctx, et_codebook *out);
+
+/* The -d self-check of encode.zig:221-247: every ordered pair (i, j) of coded symbols for which the
+ * reference's loop finds one code a prefix of the other (pairs[2k] = i, pairs[2k+1] = j, in the reference's
+ * i-then-j order; *n_pairs = how many there are, also beyond cap_pairs).  The reference prints "Found
+ * colliding prefix codes for {i} {c} and {j} {c}" for each; a Huffman table never has any. */
+int et_prefix_collisions(const et_codebook *cb, uint8_t *pairs, size_t cap_pairs, size_t *n_pairs);
 
 /* The four bytes decode() never sees (main.zig:204 passes text_in[4..] unchecked, TODO at
  * main.zig:199): magic e7 c0 de and format version 01 (encode.zig:262-266).  ET_OK, or
@@ -255,6 +265,84 @@ int et_decode_range_write(et_ctx *ctx, uint64_t max_symbols, void *d_out, size_t
 int et_decode_range_maps(et_ctx *ctx, const et_codebook *cb, const void *d_range, size_t range_bytes, size_t tail_bytes,
                          int32_t in_start_bit, uint8_t map[32], uint32_t *n_starts);
 int et_decode_range_resolve(et_ctx *ctx, uint32_t in_start_bit, et_range_info *info);
+
+/* ---- groups: one stream over the GPUs of a node ------------------------------------------------ */
+/* The reference has one thread and one buffer (encode.zig:25-337); north_star shards the text by
+ * contiguous chunk over the GPUs.  An et_group is one rank's membership: its ctx (one GPU), its rank,
+ * and how the ranks exchange small host buffers -- a callback (MPI, gloo, threads: anything that can
+ * all-gather `bytes_per_rank` bytes) or RCCL over xGMI (loaded with dlopen on first use; a process that
+ * already holds an RCCL, e.g. PyTorch's, shares it).  All ranks make the same calls in the same order. */
+typedef struct et_group et_group;
+/* send: bytes_per_rank bytes of this rank; recv: world x bytes_per_rank, rank order.  0 = success. */
+typedef int (*et_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+#define ET_RCCL_ID_BYTES 128
+int et_group_create(et_ctx *ctx, int rank, int world, et_allgather_fn allgather, void *user, et_group **group);
+/* RCCL: rank 0 obtains an id (ncclGetUniqueId) and hands it to the others out of band (the launcher's
+ * store, a file, MPI); every rank then calls et_group_create_rccl with it (ncclCommInitRank).
+ * ET_ERR_RCCL when librccl.so cannot be loaded or the communicator cannot be made. */
+int et_rccl_unique_id(uint8_t id[ET_RCCL_ID_BYTES]);
+int et_group_create_rccl(et_ctx *ctx, int rank, int world, const uint8_t id[ET_RCCL_ID_BYTES], et_group **group);
+void et_group_destroy(et_group *group);
+const char *et_group_last_error(const et_group *group);
+
+/* Where this rank's shard sits in the .et image.  Bits and words are counted from the image's first
+ * byte; a "word" is 4 bytes.  The rank's buffer holds words [piece_word_lo, piece_word_hi) (word
+ * piece_word_lo at d_out[0]); it CONTRIBUTES words [owned_word_lo, owned_word_hi): a word two shards
+ * share belongs to the first of them. */
+typedef struct et_shard_info {
+    uint64_t start_bit, end_bit;      /* the shard's body: image bits [start_bit, end_bit) */
+    uint64_t local_start_bit;         /* bit of d_out at which that body begins (rank 0: 8 x header_len; else start_bit % 32) */
+    uint64_t header_len;              /* rank 0: bytes of header + dictionary in front of its body; else 0 */
+    uint64_t file_bytes;              /* length of the whole image (encode.zig:318,336) */
+    uint64_t text_len;                /* bytes of text over all ranks */
+    uint64_t piece_word_lo, piece_word_hi, owned_word_lo, owned_word_hi;
+    float exchange_ms, plan_ms;       /* host clock: the histogram all-gather (incl. the wait for K1); code table + header + offsets */
+    float seam_ms, concat_ms;         /* host clock: et_shard_merge_seams; the last et_shard_write_fd / et_shard_gather */
+} et_shard_info;
+
+/* encode() (encode.zig:25-337) for one rank's chunk d_text[0..n) of the group's text: local histogram
+ * (K1), ONE exchange (all-gather of the 256 x u64 local histograms: their sum is encode.zig:43-47's
+ * histogram, each row gives a shard's bit count), the same code table, header and offsets on every rank
+ * (et_plan_shards), then the shard's body at its bit offset (K2 + K4).  d_out: 4-byte aligned, cap >=
+ * et_encode_bound(n).  A rank may hold no text (n = 0).  ET_ERR_EMPTY when all ranks are empty. */
+int et_encode_sharded(et_group *group, const void *d_text, size_t n, void *d_out, size_t cap, et_shard_info *info);
+/* The bit-offset-adjusted concatenation (encode.zig:319 writes ONE image).  After et_encode_sharded:
+ * et_shard_merge_seams -- the owner of a word that several shards share receives their bits (one exchange
+ * of 8 bytes per rank; d_out's last word is patched on the device).  From then on the ranks' owned words
+ * are disjoint ranges of the image and travel independently:
+ * et_shard_write_fd   pwrite this rank's owned bytes at their offset of `fd` (any rank order; rank-local),
+ * et_shard_place      copy them into an image in device memory this rank can address (same GPU, or a
+ *                     peer-mapped pointer), on the ctx stream,
+ * et_shard_gather     RCCL groups: every rank's owned words to `root`'s d_image over xGMI (send/recv;
+ *                     d_image and cap are read on root only; cap >= file_bytes rounded up to 4). */
+int et_shard_merge_seams(et_group *group, void *d_out);
+int et_shard_write_fd(et_group *group, const void *d_out, int fd);
+int et_shard_place(et_group *group, const void *d_out, void *d_image, size_t cap);
+int et_shard_gather(et_group *group, const void *d_out, void *d_image, size_t cap, int root);
+/* The plan of the group's last et_encode_sharded: code table, the world + 1 shard offsets, this rank's info
+ * (with the timings of the calls made since). */
+int et_group_codebook(const et_group *group, et_codebook *cb);
+int et_group_start_bits(const et_group *group, uint64_t *start_bits);
+int et_group_last_info(const et_group *group, et_shard_info *info);
+/* The host arithmetic of the concatenation, on its own (tests, other hosts): words[4] = {piece_lo, piece_hi,
+ * owned_lo, owned_hi} of `rank`; et_seam_word: the word that closes `rank`'s owned range with the bits of
+ * every later shard that begins in it (first_last = per rank {first word, last word} of its buffer, own bits
+ * only); *has_seam = 0 when the rank shares no word it owns. */
+int et_shard_words(const uint64_t *start_bits, uint32_t world, uint32_t rank, uint64_t words[4]);
+int et_seam_word(const uint64_t *start_bits, uint32_t world, uint32_t rank, const uint32_t *first_last, uint32_t *merged, int *has_seam);
+/* d_src[0..len) -> fd at file_offset, and back, through the ctx's pinned staging (pwrite / pread in chunks,
+ * overlapped with the copies; main.zig:34-40 and encode.zig:319 for one rank's part of a file). */
+int et_device_to_fd(et_ctx *ctx, const void *d_src, size_t len, int fd, uint64_t file_offset);
+int et_fd_to_device(et_ctx *ctx, int fd, uint64_t file_offset, size_t len, void *d_dst);
+
+/* decode() (decode.zig:13-220) of ONE cold stream by the ranks of a group: d_compressed = the .et file
+ * minus its first 4 bytes, resident on every rank (at least its own 8 KiB-block range with 16 bytes on
+ * either side, and the first 8 KiB for the dictionary).  Rank r decodes blocks [r, r+1) x n_blocks / world:
+ * *written symbols into d_out, the first of which is symbol *first_index of the text (the output stays
+ * sharded).  One exchange of (start, exit, symbols) per round (expected: one round); codes that do not
+ * self-synchronise exchange their 32-byte exit maps instead. */
+int et_decode_sharded(et_group *group, const void *d_compressed, size_t len, void *d_out, size_t cap, size_t *written,
+                      uint64_t *first_index);
 
 #ifdef __cplusplus
 }

@@ -194,3 +194,45 @@ def test_cold_decode_block_plan_keeps_16_bytes_behind_every_inner_range():
                 if hi > lo:
                     end = nbytes if hi == n_blocks else hi * 8192
                     assert end == nbytes or nbytes - end >= 16
+
+
+def test_prefix_collision_check_follows_the_reference_loop():
+    """et_prefix_collisions = encode.zig:221-247, including its k = 0 round (the bit above each code) and the
+    u5 truncation of the bit index: compared with the loop restated here on crafted tables."""
+    import ctypes
+
+    from entreepy_amd import _native as N
+    from entreepy_amd.codec import Codebook
+
+    def reference_loop(data, length):
+        out = []
+        for i in range(256):
+            for j in range(256):
+                if length[i] == 0 or length[j] == 0 or i == j:
+                    continue
+                shorter = min(int(length[i]), int(length[j]))
+                if all(((int(data[i]) >> ((int(length[i]) - k) & 31)) & 1) == ((int(data[j]) >> ((int(length[j]) - k) & 31)) & 1) for k in range(shorter + 1)):
+                    out.append((i, j))
+        return out
+
+    rng = np.random.default_rng(11)
+    tables = []
+    d, l = np.zeros(256, dtype=np.uint32), np.zeros(256, dtype=np.uint8)
+    d[65], l[65], d[66], l[66], d[67], l[67] = 0b1, 1, 0b11, 2, 0b0, 1  # "1" is a prefix of "11"
+    tables.append((d, l))
+    for _ in range(20):  # random tables, lengths up to 40 (the truncated index matters above 31)
+        d, l = np.zeros(256, dtype=np.uint32), np.zeros(256, dtype=np.uint8)
+        for s in rng.choice(256, size=12, replace=False):
+            l[s] = rng.integers(1, 41)
+            d[s] = rng.integers(0, 1 << 32, dtype=np.uint64) & ((1 << min(int(l[s]), 32)) - 1)
+        tables.append((d, l))
+    hits = 0
+    for d, l in tables:
+        cb = Codebook.from_tables(d, l)
+        pairs = np.zeros(2 * 256 * 255, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        assert N.lib().et_prefix_collisions(ctypes.byref(cb.raw), pairs.ctypes.data, pairs.size // 2, ctypes.byref(n)) == 0
+        got = [(int(pairs[2 * k]), int(pairs[2 * k + 1])) for k in range(n.value)]
+        assert got == reference_loop(d, l)
+        hits += len(got)
+    assert (65, 66) in reference_loop(*tables[0]) and hits > 2
