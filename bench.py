@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=int(os.environ.get("ET_BENCH_BYTES", 1 << 30)), help="text bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the chunk-parallel CPU baseline (0: min(cores, 16))")
+    ap.add_argument("--no-second-workload", action="store_true", help="skip the enwik-like stream measured after the headline (N=1)")
     args = ap.parse_args()
 
     import torch
@@ -142,7 +143,18 @@ def main():
             dist.init_process_group(backend)
 
     n = args.bytes
-    text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev)
+    # The metric's stream: a real corpus when the environment names one ($ET_CORPUS_ENWIK9, BASELINE config 4;
+    # rank r takes the r-th n-byte slice), else the synthetic text-1G.
+    real = corpus.from_env("ET_CORPUS_ENWIK9")
+    if real is not None and real.size >= (rank + 1) * min(n, real.size // world):
+        n = min(n, real.size // world)
+        text = torch.from_numpy(real[rank * n : (rank + 1) * n].copy()).to(dev)
+        workload_name = f"enwik9 ($ET_CORPUS_ENWIK9): {n} B per GPU"
+    else:
+        text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev)
+        workload_name = (f"text-1G: {n} B per GPU, order-0 samples of a_midsummer_nights_dream.txt's byte distribution "
+                         f"(seed 0x5EED0004+rank)")
+    del real
     ctx = E.Context(local)
     ctx.use_torch_stream()
     ctx.reserve(n)
@@ -203,6 +215,60 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # N > 1: the bit-offset-adjusted concatenation of the shards into ONE image on rank 0 (seam merge + owned
+    # words over xGMI), timed on its own after the headline region -- it is not part of `value`.
+    concat_ms = seam_ms = None
+    if world > 1:
+        best = None
+        for _ in range(3):
+            r = pipe.encode_shard(text, enc, timings=False)
+            torch.cuda.synchronize()
+            barrier()
+            tc0 = time.perf_counter()
+            image = pipe.concat_on_rank0(enc, r)
+            torch.cuda.synchronize()
+            barrier()
+            dt = (time.perf_counter() - tc0) * 1e3
+            best = dt if best is None else min(best, dt)
+            del image
+        tmax = torch.tensor([best], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        concat_ms = float(tmax.item())
+        seam_ms = pipe.lib_group.info()["seam_ms"] if pipe.lib_group is not None else None
+
+    # N = 1: a second stream, enwik-like (206 symbols, code lengths up to 24: the long codes the text stream never
+    # shows), same step, a few repetitions -- reported beside the headline, never instead of it.
+    second = None
+    if world == 1 and not force_group and not args.no_second_workload:
+        del text
+        torch.cuda.empty_cache()
+        text2 = corpus.enwik_like_torch(n, 0x5EED0009, dev)
+        ph2 = {"hist": 0.0, "enc_scan": 0.0, "enc_body": 0.0, "enc_total": 0.0, "dec_sync_first": 0.0, "dec_body": 0.0, "dec_total": 0.0}
+        reps = 6
+        for i in range(reps + 2):
+            r2 = pipe.encode_shard(text2, enc, timings=False)
+            m2 = pipe.decode_shard(enc, r2, dec)
+            te, td = pipe.encode_timings(), ctx.timings("decode")
+            if i >= 2:
+                for k in ("hist", "enc_scan", "enc_body", "enc_total"):
+                    ph2[k] += te[k]
+                ph2["dec_sync_first"] += td["sync_first_ms"]
+                ph2["dec_body"] += td["body_ms"]
+                ph2["dec_total"] += td["total_ms"]
+        torch.cuda.synchronize()
+        assert m2 == n and torch.equal(dec[:n], text2), "enwik-like round trip is not the identity"
+        cb2 = ctx.last_codebook()
+        p2 = {k: v / reps for k, v in ph2.items()}
+        second = {
+            "workload": f"enwik-like: {n} B, 206 symbols (96 Zipf-like + 110 with probabilities 2^-12 .. 2^-24), seed 0x5EED0009",
+            "symbols": int(cb2.raw.n_coded), "code_lengths": [int(cb2.raw.min_length), int(cb2.raw.max_length)],
+            "packed_bytes": r2["body_bytes"],
+            "encode_GBps": round(n / (p2["enc_total"] * 1e-3) / 1e9, 2), "decode_GBps": round(n / (p2["dec_total"] * 1e-3) / 1e9, 2),
+            "round_trip_GBps": round(n / ((p2["enc_total"] + p2["dec_total"]) * 1e-3) / 1e9, 2),
+            "phase_ms": {k: round(v, 4) for k, v in p2.items()},
+        }
+        text = text2
+
     if rank == 0:
         K = args.steps
         ms = {k: v / K for k, v in phases.items()}
@@ -237,8 +303,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"text-1G: {n} B per GPU, order-0 samples of a_midsummer_nights_dream.txt's byte distribution "
-                            f"(seed 0x5EED0004+rank), one step = encode to .et + decode back, HBM-resident",
+                "workload": workload_name + ", one step = encode to .et + decode back, HBM-resident",
                 "bytes_per_gpu": n,
                 "packed_bytes_per_gpu": m_bytes,
                 "sharding": "1 stream" if world == 1 else f"{world} contiguous shards of one stream, one RCCL all-gather of the local histograms per step (sum = global histogram, rows = shard bit counts)",
@@ -263,7 +328,14 @@ def main():
             "kernels": {k: {"ms_per_launch": round(v[0], 4), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] else None,
                             "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if v[0] else None} for k, v in kernels.items()},
         }
+        if concat_ms is not None:
+            out["concat_ms"] = round(concat_ms, 4)     # seams merged + every rank's owned words on rank 0's GPU, max over ranks, best of 3
+            out["seam_ms"] = None if seam_ms is None else round(seam_ms, 4)
+            out["exchange_ms"] = round(ms["exchange"], 4)  # the histogram all-gather of every step (host clock, incl. the wait for K1)
+        if second is not None:
+            out["workloads"] = {"enwik-like": second}
         if world == 1 and not args.no_cpu_baseline:
+            text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev) if second is not None else text  # the headline stream again
             host_text = text[: min(n, 1 << 30)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host_text[: 768 << 20])
             out["cpu_baseline_parallel"] = cpu_baseline_parallel(host_text, args.cpu_threads)

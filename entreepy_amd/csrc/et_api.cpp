@@ -15,6 +15,7 @@
 #include "et_io.h"
 #include "et_kernels.h"
 #include "et_tables.h"
+#include "et_treewalk.h"
 
 #include <hip/hip_runtime.h>
 
@@ -58,6 +59,8 @@ struct et_ctx {
     // decode workspaces
     DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag, worklist;  // flag: [0..3] sweep flags, [4] ticket, [8..] worklist counts  // lut: all decode tables, DEC_TABLES_BYTES
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
+    DevBuf tw_table, tw_tree, blk_start;                   // tree-walk synchronisation (et_treewalk.h)
+    et::TwTree *h_tw_tree[2] = {};                         // pinned, used in turn like h_lut_buf
     // staging for the host-pointer / file-descriptor entry points
     DevBuf io_in, io_out;
     et_io::Pipe *io = nullptr;  // pinned double buffer + copy threads, made on first use
@@ -319,6 +322,7 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     }
     ctx->h_lut = ctx->h_lut_buf[0];
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 16 * sizeof(uint64_t)) == hipSuccess;
+    for (int i = 0; i < 2; ++i) ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tw_tree[i]), sizeof(et::TwTree)) == hipSuccess;
     // timing-only events: no system-scope fence when they complete (hip_runtime_api.h: "for events that
     // are only being used to measure timing"); with the default flags the ten records of an
     // encode+decode cost ~65 us of cache write-backs and waits at 1 GiB
@@ -339,11 +343,11 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->group_sum,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->flag,
                       &ctx->worklist, &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
-                      &ctx->io_in, &ctx->io_out};
+                      &ctx->tw_table, &ctx->tw_tree, &ctx->blk_start, &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     delete ctx->io;
-    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_header, ctx->h_lut_buf[0], ctx->h_lut_buf[1], ctx->h_scalar};
+    void *pinned[] = {ctx->h_hist, ctx->h_enc, ctx->h_header, ctx->h_lut_buf[0], ctx->h_lut_buf[1], ctx->h_scalar, ctx->h_tw_tree[0], ctx->h_tw_tree[1]};
     for (void *p : pinned)
         if (p) (void)hipHostFree(p);
     for (auto &e : ctx->ev)
@@ -441,6 +445,9 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->group_sum, (n_blocks / 1024 + 2) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
+    ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
+    ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwTree)));
+    ET_TRY(ensure(ctx, ctx->blk_start, n_blocks * sizeof(uint32_t)));
     return ET_OK;
 }
 
@@ -898,16 +905,50 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     // A (nearly) fixed-length code has nothing to re-synchronise on: do not even try.
     bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
     bool more_sweeps = false;
+    // The synchronisation sweeps by tree walk (et_treewalk.h) when the code table is a full tree -- an
+    // encoder's always is -- and the stream is more than a few blocks; the register-window sweeps otherwise.
+    uint32_t *blk_start = nullptr;
+    const uint16_t *tw_table = nullptr;
+    uint32_t tw_n_int = 0;
+    if (!exhaustive && n_blocks >= 16) {
+        et::TwTree *h_tree = ctx->h_tw_tree[ctx->lut_turn];  // (prepare_decode_tables has just flipped the turn: this one is free)
+        if (et::tw_build_tree(cb, h_tree) == ET_OK) {
+            ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
+            ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwTree)));
+            ET_TRY(ensure(ctx, ctx->blk_start, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            tw_n_int = h_tree->n_int;
+            ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, h_tree, 8 + 4 * static_cast<size_t>(tw_n_int), hipMemcpyHostToDevice, ctx->stream));
+            et::launch_tw_build(ctx->stream, static_cast<const et::TwTree *>(ctx->tw_tree.p), tw_n_int, static_cast<uint16_t *>(ctx->tw_table.p));
+            tw_table = static_cast<const uint16_t *>(ctx->tw_table.p);
+            blk_start = static_cast<uint32_t *>(ctx->blk_start.p);
+        }
+    }
+    auto scan_and_total_tw = [&]() -> int {
+        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off, reinterpret_cast<unsigned long long *>(flag + 12), blk_start, blk_exit, flag + 2, 0u,
+                            flag, h_flags, true);
+        ET_HIP(hipGetLastError());
+        ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
+        return ET_OK;
+    };
     if (!exhaustive) {
         if (!flags_zeroed) ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
         write_ticket_zero = true;
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
-                            et::DEC_HAVE_START, nullptr, nullptr, side, true, timed(ctx, EV_DEC + 0, EV_DEC + 5));
-        et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
-                            et::DEC_HAVE_START, worklist, flag + 8, side);
+        if (tw_table) {
+            et::launch_tw_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tw_table, tw_n_int, sub_state, blk_exit, blk_start, blk_count, flag,
+                               et::DEC_FIRST_SWEEP_TRIPS, nullptr, nullptr, timed(ctx, EV_DEC + 0, EV_DEC + 5));
+            et::launch_tw_check(ctx->stream, blk_start, blk_exit, n_blocks, worklist, flag + 8);
+            et::launch_tw_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tw_table, tw_n_int, sub_state, blk_exit, blk_start, blk_count, flag,
+                               et::DEC_REPAIR_SWEEP_TRIPS, worklist, flag + 8);
+        } else {
+            et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
+                                et::DEC_HAVE_START, nullptr, nullptr, side, true, timed(ctx, EV_DEC + 0, EV_DEC + 5));
+            et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 1, et::DEC_REPAIR_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
+                                et::DEC_HAVE_START, worklist, flag + 8, side);
+        }
         ET_HIP(hipGetLastError());
         iters = 3;  // run-in sweep, repair sweep, verification
-        ET_TRY(scan_and_total(true));
+        if (tw_table) ET_TRY(scan_and_total_tw());
+        else ET_TRY(scan_and_total(true));
         if (can_speculate) {
             ET_TRY(write_symbols(n_symbols, true));
             wrote = true;
@@ -939,6 +980,11 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     while (more_sweeps) {
         ET_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
         ET_HIP(hipMemsetAsync(flag + 8, 0, sizeof(uint32_t), ctx->stream));
+        if (tw_table) {
+            et::launch_tw_check(ctx->stream, blk_start, blk_exit, n_blocks, worklist, flag + 8);
+            et::launch_tw_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tw_table, tw_n_int, sub_state, blk_exit, blk_start, blk_count, flag, 0xffffffffu,
+                               worklist, flag + 8);
+        } else
         et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, iters, 0xffffffffu, sub_state, blk_exit, blk_count, flag, flag + 4,
                             et::DEC_HAVE_START, worklist, flag + 8);
         ET_HIP(hipGetLastError());

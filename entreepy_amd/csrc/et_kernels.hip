@@ -246,14 +246,16 @@ template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out,
                                                      unsigned long long *__restrict__ group_sum, const uint32_t *__restrict__ verify_state,
                                                      const uint32_t *__restrict__ verify_exit, uint32_t *__restrict__ verify_flag,
-                                                     uint32_t verify_first) {
+                                                     uint32_t verify_first, uint32_t verify_stride, uint32_t verify_mask) {
     __shared__ unsigned long long wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i = blockIdx.x * 1024 + tid;
     // (block 0 must have started at verify_first, the stream's known first bit; 0xffffffff: not checked)
     if (verify_state && i < n) {
         const uint32_t want = i > 0 ? verify_exit[i - 1] : verify_first;
-        if (want != 0xffffffffu && (verify_state[static_cast<uint64_t>(i) * BLOCK] & 0xffu) != want) *verify_flag = 1;
+        // (verify_state: the start each block's first lane used -- sub_state, every BLOCK-th entry's low byte, a bit
+        // offset; or the tree walk's blk_start, a row -- against what the block before ended on)
+        if (want != 0xffffffffu && (verify_state[static_cast<uint64_t>(i) * verify_stride] & verify_mask) != want) *verify_flag = 1;
     }
     const unsigned long long x = (i < n) ? static_cast<unsigned long long>(in[i]) : 0ull;
     const unsigned long long inc = wave_inclusive_scan64(x);
@@ -2026,7 +2028,7 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
     if (grid > MAX_GRID) grid = MAX_GRID;
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
     const uint32_t groups = (n_tiles + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), 0xffffffffu);
+    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), 0xffffffffu, 0u, 0u);
     hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), header_src, header_words);
 }
 
@@ -2292,9 +2294,10 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
                      unsigned long long *blk_off, unsigned long long *total_copy, const uint32_t *verify_state, const uint32_t *verify_exit,
-                     uint32_t *verify_flag, uint32_t verify_first, const uint32_t *report_src, uint32_t *report_dst) {
+                     uint32_t *verify_flag, uint32_t verify_first, const uint32_t *report_src, uint32_t *report_dst, bool verify_rows) {
     const uint32_t groups = (n_blocks + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag, verify_first);
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag, verify_first,
+                       verify_rows ? 1u : static_cast<uint32_t>(BLOCK), verify_rows ? 0xffffffffu : 0xffu);
     hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy, report_src, report_dst, static_cast<const uint32_t *>(nullptr), 0u);
 }
 

@@ -1,0 +1,389 @@
+// et_treewalk.hip -- D1 by fixed-rate tree walk (format and rationale: et_treewalk.h), gfx950 / wave64.
+//
+//   decode.zig:143-203 -> k_tw_sync: where do codewords begin, and how many begin in each 256 bits?
+//
+// A wavefront owns one 8 KiB block: 128 lanes of 512 bits held in registers, thread t walks lanes t and
+// 64 + t (two dependent chains in flight per thread: a step is an LDS round trip, ~200 cycles under the
+// ~3.5-way bank conflicts of random lookups, and nothing else hides it).  Every lane runs in over the 128
+// bits before its own, then walks its 64 bytes; lanes of a block agree on the tree node at their seams by a
+// fixed point over shuffles.  After the table is staged nothing is shared between wavefronts: no barrier, no
+// LDS traffic besides the lookups, no ticket.  The chain per step is table read -> shift -> and-or -> table
+// read; the byte positions are compile-time constants.
+#include "et_treewalk.h"
+
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+namespace et {
+
+// ALL LDS of k_tw_sync is the dynamic block (cdna_hip_programming.md Guideline 17): the table, at LDS address 0.
+extern __shared__ __attribute__((aligned(16))) uint8_t tw_smem[];
+typedef __attribute__((address_space(3))) uint8_t tw_lds_u8;
+typedef __attribute__((address_space(3))) uint16_t tw_lds_u16;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t tw_dpp_add(uint32_t x) {
+    return x + static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ uint32_t tw_wave_inclusive_scan(uint32_t x) {
+    x = tw_dpp_add<0x111, 0xf>(x);  // row_shr:1
+    x = tw_dpp_add<0x112, 0xf>(x);  // row_shr:2
+    x = tw_dpp_add<0x114, 0xf>(x);  // row_shr:4
+    x = tw_dpp_add<0x118, 0xf>(x);  // row_shr:8
+    x = tw_dpp_add<0x142, 0xa>(x);  // row_bcast:15
+    x = tw_dpp_add<0x143, 0xc>(x);  // row_bcast:31
+    return x;
+}
+
+// Word `idx` (may be negative: before `words`) of the stream in host order, zero outside it.
+__device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__restrict__ words, long long idx, uint64_t n_bytes) {
+    if (idx < 0) return 0u;
+    const uint64_t b0 = static_cast<uint64_t>(idx) * 4;
+    if (b0 + 4 <= n_bytes) return __builtin_bswap32(words[idx]);
+    uint32_t v = 0;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(words);
+    for (int k = 0; k < 4; ++k)
+        if (b0 + k < n_bytes) v |= static_cast<uint32_t>(bytes[b0 + k]) << (24 - 8 * k);
+    return v;
+}
+
+// ---- the table, filled on the device from the tree -------------------------------------------------
+__global__ __launch_bounds__(1024) void k_tw_build(const TwTree *__restrict__ tree, uint32_t n_int, uint16_t *__restrict__ table) {
+    __shared__ int16_t child[2 * TW_MAX_NODES];
+    for (uint32_t i = threadIdx.x; i < 2 * n_int; i += 1024) child[i] = tree->child[i];
+    __syncthreads();
+    const uint32_t entries = tw_table_entries(n_int);
+    for (uint32_t idx = blockIdx.x * 1024 + threadIdx.x; idx < entries; idx += gridDim.x * 1024) {
+        const uint32_t r = idx >> 8, f = idx & 255u;
+        uint32_t node = r < n_int ? r : 0, n = 0, first = 0;
+        const uint32_t skip = r < n_int ? 0 : r - n_int + 1;
+        for (uint32_t i = skip; i < 8; ++i) {
+            const int c = child[2 * node + ((f >> (7 - i)) & 1u)];
+            if (c >= 0) {
+                node = static_cast<uint32_t>(c);
+            } else {
+                if (n++ == 0) first = i;
+                node = 0;
+            }
+        }
+        table[idx] = static_cast<uint16_t>(node | (n << TW_N_SHIFT) | (first << TW_OFF_SHIFT));
+    }
+}
+
+// ---- the walk -------------------------------------------------------------------------------------
+constexpr int TW_WORDS = 21;  // W[j] = stream word 16 * lane - 4 + j: 4 run-in words, 16 own, 1 beyond (a block's tail at the stream's end)
+constexpr int TW_LANES = 2;   // 512-bit lanes walked by one thread
+
+struct TwTrack {  // where the subsequence's first codeword begins: the bit after the first completion
+    bool found[TW_LANES];
+    uint32_t start[TW_LANES];
+};
+
+// N_STEPS bytes from bit BIT0 of both lanes' words: R = row byte offset (row << 9), C += codewords completed.
+// EDGE: only the steps below `limit` count (the stream ends inside the lane's bytes); SKIP: steps below
+// `skip` do not count either (a walk that begins at a bit offset); TRACK: the first four steps also look for
+// the first completion.
+template <int BIT0, int N_STEPS, bool EDGE, bool SKIP, bool TRACK>
+__device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS], uint32_t (&R)[TW_LANES], uint32_t (&C)[TW_LANES],
+                                        const uint32_t (&skip)[TW_LANES], const uint32_t (&limit)[TW_LANES], int step0, TwTrack &t) {
+    const uint32_t tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((tw_lds_u8 *)tw_smem));
+#pragma unroll
+    for (int j = 0; j < N_STEPS; ++j) {
+#pragma unroll
+        for (int u = 0; u < TW_LANES; ++u) {
+            const int bit = BIT0 + 8 * j;
+            const uint32_t f2 = ((W[u][bit >> 5] >> (24 - (bit & 31))) & 0xffu) << 1;
+            const uint32_t e = *reinterpret_cast<const tw_lds_u16 *>(static_cast<uintptr_t>(tab + (R[u] | f2)));
+            bool on = true;
+            if (EDGE) on = on && static_cast<uint32_t>(step0 + j) < limit[u];
+            if (SKIP && j < 4) on = on && static_cast<uint32_t>(j) >= skip[u];
+            const uint32_t next = (e << 9) & (TW_ROW_MASK << 9);
+            uint32_t n = (e >> TW_N_SHIFT) & 15u;
+            if (EDGE || (SKIP && j < 4)) {
+                R[u] = on ? next : R[u];
+                n = on ? n : 0u;
+            } else {
+                R[u] = next;
+            }
+            if (TRACK && j < 4) {
+                const bool hit = !t.found[u] && n > 0;
+                t.start[u] = hit ? 8u * j + (e >> TW_OFF_SHIFT) + 1u : t.start[u];
+                t.found[u] = t.found[u] || n > 0;
+            }
+            // (added here and now: left to itself the compiler keeps every entry of the walk alive and sums them at the end, out of scratch memory)
+            asm volatile("v_add_u32 %0, %0, %1" : "+v"(C[u]) : "v"(n));
+        }
+        // (nothing moves across a step: the compiler otherwise computes every byte offset of the walk up front and spills)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct TwLane {
+    uint32_t s_mid, s_out;  // rows after 256 bits, after 512
+    uint32_t c1, c2;        // codewords completed in the first / second 256 bits
+};
+
+// Both lanes of a thread from row offsets R0.  `take[u]`: lane u's results are wanted; REWALK: a lane that
+// stands after 256 bits where its old walk stood keeps the rest.
+template <bool EDGE, bool REWALK>
+__device__ __forceinline__ void tw_lanes(uint32_t (&W)[TW_LANES][TW_WORDS], const uint32_t (&R0)[TW_LANES], const uint32_t (&skip)[TW_LANES],
+                                         const uint32_t (&limit)[TW_LANES], const bool (&take)[TW_LANES], TwLane (&r)[TW_LANES]) {
+    // (the words are "new" to every walk: the compiler otherwise keeps the first walk's byte offsets for the re-walk, in scratch memory)
+#pragma unroll
+    for (int u = 0; u < TW_LANES; ++u)
+#pragma unroll
+        for (int j = 4; j < TW_WORDS; ++j) asm volatile("" : "+v"(W[u][j]));
+    uint32_t R[TW_LANES], C[TW_LANES];
+    bool redo[TW_LANES];
+    bool any_redo = false;
+    TwTrack t = {};
+#pragma unroll
+    for (int u = 0; u < TW_LANES; ++u) {
+        R[u] = R0[u];
+        C[u] = 0;
+    }
+    tw_walk<128, 32, EDGE, true, false>(W, R, C, skip, limit, 0, t);
+#pragma unroll
+    for (int u = 0; u < TW_LANES; ++u) {
+        if (EDGE && limit[u] < 32) R[u] = 0;  // the stream ended: nothing is pending
+        const uint32_t mid = R[u] >> 9;
+        redo[u] = take[u] && !(REWALK && mid == r[u].s_mid);
+        if (take[u]) {
+            r[u].c1 = C[u];
+            r[u].s_mid = mid;
+        }
+        C[u] = 0;
+        any_redo = any_redo || redo[u];
+    }
+    if (__any(any_redo)) {
+        tw_walk<384, 32, EDGE, false, false>(W, R, C, skip, limit, 32, t);
+#pragma unroll
+        for (int u = 0; u < TW_LANES; ++u) {
+            if (EDGE && limit[u] < 64) R[u] = 0;
+            if (redo[u]) {
+                r[u].c2 = C[u];
+                r[u].s_out = R[u] >> 9;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_tw_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
+                                                    uint32_t n_blocks, const uint16_t *__restrict__ table, uint32_t table_entries, uint32_t n_int,
+                                                    uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_start,
+                                                    uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed, uint32_t max_trips,
+                                                    const uint32_t *__restrict__ worklist, const uint32_t *__restrict__ n_work) {
+    uint16_t *tab = reinterpret_cast<uint16_t *>(tw_smem);
+    const uint32_t T = blockDim.x, tid = threadIdx.x, lane_id = tid & 63;
+    const uint32_t n_todo = worklist ? *n_work : n_blocks;
+    if (blockIdx.x * (T >> 6) >= n_todo) return;  // (a repair sweep usually has a handful of blocks)
+    for (uint32_t i = tid * 8; i < table_entries; i += T * 8) *reinterpret_cast<uint4 *>(tab + i) = *reinterpret_cast<const uint4 *>(table + i);
+    __syncthreads();
+    const uint64_t n_lanes = (n_subs + 1) / 2;
+    const uint64_t n_words_full = n_bytes / 4;
+    const uint32_t waves_per_group = T >> 6;
+    for (uint32_t it = blockIdx.x * waves_per_group + (tid >> 6); it < n_todo; it += gridDim.x * waves_per_group) {
+        const uint32_t b = worklist ? worklist[it] : it;
+        // wavefront-uniform: every word of the block, its run-in and the word after it is a whole word of the stream
+        const long long bw0 = static_cast<long long>(b) * 2048 - 4;
+        const bool edge = bw0 < 0 || static_cast<uint64_t>(bw0 + 2048 + 4 + 1) > n_words_full;
+        uint32_t W[TW_LANES][TW_WORDS], limit[TW_LANES];
+        uint64_t q[TW_LANES];
+        bool live[TW_LANES];
+#pragma unroll
+        for (int u = 0; u < TW_LANES; ++u) {
+            q[u] = static_cast<uint64_t>(b) * 128 + u * 64 + lane_id;  // 512-bit lane = subsequences 2q, 2q + 1
+            live[u] = q[u] < n_lanes;
+            limit[u] = 0xffffffffu;
+            const long long w0 = static_cast<long long>(q[u]) * 16 - 4;
+            if (!edge) {
+#pragma unroll
+                for (int j = 0; j < TW_WORDS; ++j) W[u][j] = __builtin_bswap32(words[w0 + j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TW_WORDS; ++j) W[u][j] = tw_load_guarded(words, w0 + j, n_bytes);
+                // whole bytes of the stream inside the lane's own 64 -> steps that count
+                const uint64_t lane_byte0 = q[u] * 64;
+                limit[u] = static_cast<uint32_t>(n_bytes > lane_byte0 ? (n_bytes - lane_byte0 < 64 ? n_bytes - lane_byte0 : 64) : 0);
+            }
+        }
+        // run-in: from the root, 128 bits before the lane's own
+        uint32_t R0[TW_LANES] = {}, skip[TW_LANES] = {}, C0[TW_LANES] = {};
+        const uint32_t no_limit[TW_LANES] = {0xffffffffu, 0xffffffffu};
+        {
+            TwTrack none = {};
+            tw_walk<0, 16, false, false, false>(W, R0, C0, skip, no_limit, 0, none);
+        }
+        // The block's first lane may KNOW where it begins: the stream's first lane (the root at bit first_bit),
+        // or, in a repair sweep, the node the block before ends in.
+        const bool first_lane = lane_id == 0;
+        bool known_bit = false;
+        if (first_lane && b == 0) {
+            known_bit = true;
+            skip[0] = first_bit / 8;
+            const uint32_t rem = first_bit % 8;
+            R0[0] = rem ? (n_int + rem - 1) << 9 : 0u;
+        } else if (first_lane && worklist) {
+            R0[0] = blk_exit[b - 1] << 9;
+        }
+        uint32_t start[TW_LANES];  // the row each lane's walk begins in (0 also for a known bit offset: it is a codeword boundary)
+        TwLane r[TW_LANES] = {};
+        bool take[TW_LANES];
+#pragma unroll
+        for (int u = 0; u < TW_LANES; ++u) {
+            start[u] = (u == 0 && known_bit) ? 0u : R0[u] >> 9;
+            take[u] = true;
+        }
+        if (edge) tw_lanes<true, false>(W, R0, skip, limit, take, r);
+        else tw_lanes<false, false>(W, R0, skip, limit, take, r);
+        skip[0] = 0;
+        bool gave_up = false;
+        for (uint32_t trip = 1;; ++trip) {
+            // lane li's start must be lane li - 1's exit (li = u * 64 + lane); the block's first lane keeps its own
+            bool need[TW_LANES], any_need = false;
+            uint32_t cand[TW_LANES];
+            const uint32_t up0 = __shfl_up(r[0].s_out, 1), up1 = __shfl_up(r[1].s_out, 1), last0 = __shfl(r[0].s_out, 63);
+            cand[0] = lane_id ? up0 : start[0];
+            cand[1] = lane_id ? up1 : last0;
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) {
+                need[u] = live[u] && cand[u] != start[u];
+                any_need = any_need || need[u];
+            }
+            if (!__any(any_need)) break;
+            if (trip == max_trips) {  // a code that does not self-synchronise: the block is marked for a redo
+                gave_up = true;
+                break;
+            }
+            uint32_t Rn[TW_LANES];
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) Rn[u] = need[u] ? cand[u] << 9 : 0u;
+            if (edge) tw_lanes<true, true>(W, Rn, skip, limit, need, r);
+            else tw_lanes<false, true>(W, Rn, skip, limit, need, r);
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) start[u] = need[u] ? cand[u] : start[u];
+        }
+        // Where each subsequence's first codeword begins: one past the first completion seen from the node at
+        // its first bit -- four more steps per half, once the nodes are settled (tracked inside the walks it
+        // cost 25 registers, i.e. a third of the wavefronts).  found = false: the code that straddles the
+        // boundary is cut by the stream's end.
+        uint32_t st1[TW_LANES], st2[TW_LANES];
+        bool f1[TW_LANES], f2[TW_LANES];
+        {
+            uint32_t Ra[TW_LANES], Ca[TW_LANES] = {};
+            TwTrack ta;
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) {
+                Ra[u] = start[u] << 9;
+                ta.found[u] = start[u] == 0;  // (also the lane with a known bit offset: it begins there)
+                ta.start[u] = (u == 0 && known_bit) ? first_bit : 0u;
+            }
+            if (edge) tw_walk<128, 4, true, false, true>(W, Ra, Ca, skip, limit, 0, ta);
+            else tw_walk<128, 4, false, false, true>(W, Ra, Ca, skip, limit, 0, ta);
+            TwTrack tb;
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) {
+                st1[u] = ta.found[u] ? ta.start[u] : 0u;
+                f1[u] = ta.found[u];
+                Ra[u] = r[u].s_mid << 9;
+                tb.found[u] = r[u].s_mid == 0;
+                tb.start[u] = 0;
+            }
+            if (edge) tw_walk<384, 4, true, false, true>(W, Ra, Ca, skip, limit, 32, tb);
+            else tw_walk<384, 4, false, false, true>(W, Ra, Ca, skip, limit, 32, tb);
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) {
+                st2[u] = tb.found[u] ? tb.start[u] : 0u;
+                f2[u] = tb.found[u];
+            }
+        }
+        // Codewords that BEGIN in a subsequence = those that end in it, less the one that came in over its
+        // first bit, plus the one that leaves over its last.  The one leaving the lane's last bit: at the
+        // stream's end it may be cut (then it is nobody's): an edge block looks at the bytes after the lane.
+        bool out_ok[TW_LANES] = {true, true};
+        if (edge) {
+            uint32_t Rt[TW_LANES], Ct[TW_LANES] = {}, lim_t[TW_LANES];
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) {
+                Rt[u] = r[u].s_out << 9;
+                const uint64_t after = (q[u] + 1) * 64;
+                lim_t[u] = static_cast<uint32_t>(n_bytes > after ? (n_bytes - after < 4 ? n_bytes - after : 4) : 0);
+            }
+            TwTrack tt = {};
+            tw_walk<640, 4, true, false, false>(W, Rt, Ct, skip, lim_t, 0, tt);
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) out_ok[u] = Ct[u] > 0;
+        }
+        uint32_t sum = 0;
+        const uint32_t next_st0 = __shfl_down(st1[0], 1), next_st1 = __shfl_down(st1[1], 1), first1 = __shfl(st1[1], 0);
+#pragma unroll
+        for (int u = 0; u < TW_LANES; ++u) {
+            const uint32_t begun1 = r[u].c1 - ((start[u] != 0 && f1[u]) ? 1u : 0u) + ((r[u].s_mid != 0 && f2[u]) ? 1u : 0u);
+            const uint32_t begun2 = r[u].c2 - ((r[u].s_mid != 0 && f2[u]) ? 1u : 0u) + ((r[u].s_out != 0 && out_ok[u]) ? 1u : 0u);
+            // the start of the subsequence after this lane: the next lane's (the block's last lane: not known here, 0)
+            const uint32_t after = u == 0 ? (lane_id == 63 ? first1 : next_st0) : (lane_id == 63 ? 0u : next_st1);
+            if (live[u]) {
+                uint32_t first = st1[u];
+                if (gave_up && u == 0 && lane_id == 0) first = 0xffu;  // the marker the write kernels' launch rule knows
+                sub_state[2 * q[u]] = first | (st2[u] << 8) | (begun1 << 16);
+                if (2 * q[u] + 1 < n_subs) sub_state[2 * q[u] + 1] = st2[u] | (after << 8) | (begun2 << 16);
+                sum += begun1 + begun2;
+            }
+        }
+        sum = tw_wave_inclusive_scan(sum);
+        if (lane_id == 63) {
+            blk_count[b] = sum;
+            blk_exit[b] = r[1].s_out;  // (lanes past the stream's end stand at the root)
+        }
+        if (lane_id == 0) {
+            blk_start[b] = gave_up ? 0xffffffffu : start[0];
+            if (gave_up) atomicAdd(changed + 1, 1u);
+            if (worklist) *changed = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tw_check(const uint32_t *__restrict__ blk_start, const uint32_t *__restrict__ blk_exit, uint32_t n_blocks,
+                                                  uint32_t *__restrict__ worklist, uint32_t *__restrict__ n_work) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t want = b ? blk_exit[b - 1] : 0u;  // (the stream's first block starts at a codeword boundary)
+    if (blk_start[b] != want) worklist[atomicAdd(n_work, 1u)] = b;
+}
+
+// ---- launch wrappers --------------------------------------------------------------------------------
+void launch_tw_build(hipStream_t stream, const TwTree *d_tree, uint32_t n_int, uint16_t *table) {
+    const uint32_t entries = tw_table_entries(n_int);
+    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_tree, n_int, table);
+}
+
+void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, const uint16_t *table,
+                    uint32_t n_int, uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_start, uint32_t *blk_count, uint32_t *changed,
+                    uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev) {
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
+    const uint32_t entries = tw_table_entries(n_int);
+    const size_t smem = static_cast<size_t>(entries) * 2;
+    // workgroups of 8 wavefronts, as many per CU as the table leaves room for in the LDS, at most 3 (<= 80 VGPRs: 6
+    // wavefronts per SIMD); a table that leaves room for one workgroup only gets one of 16 wavefronts
+    static thread_local int seen_dev = -1, cus = 256;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != seen_dev) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        seen_dev = dev;
+    }
+    uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / smem);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+    const uint32_t threads = per_cu == 1 ? 1024u : 512u, waves = threads / 64;
+    uint32_t grid = static_cast<uint32_t>(cus) * per_cu;
+    if (grid > (n_blocks + waves - 1) / waves) grid = (n_blocks + waves - 1) / waves;
+    if (worklist && grid > 64) grid = 64;  // a repair sweep: a handful of blocks (workgroups beyond the list leave at once)
+    if (ev.start || ev.stop) hipExtLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, ev.start, ev.stop, 0, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work);
+    else hipLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work);
+}
+
+void launch_tw_check(hipStream_t stream, const uint32_t *blk_start, const uint32_t *blk_exit, uint32_t n_blocks, uint32_t *worklist, uint32_t *n_work) {
+    hipLaunchKernelGGL(k_tw_check, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, blk_start, blk_exit, n_blocks, worklist, n_work);
+}
+
+}  // namespace et

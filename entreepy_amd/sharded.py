@@ -288,6 +288,20 @@ class ShardedCodec:
         if merged is not None:
             enc[(hi - lo - 1) * 4 : (hi - lo) * 4] = torch.from_numpy(np.array([merged], dtype=np.uint32).view(np.uint8).copy()).to(enc.device)
 
+    def concat_on_rank0(self, enc, layout):
+        """The image as a device tensor on rank 0 (None elsewhere): seam merge + owned words over xGMI (RCCL
+        groups) -- what bench.py times as concat_ms.  Without RCCL: through gather_file's host path."""
+        if layout["single"]:
+            return enc[: layout["et_len"]]
+        if self.lib_group is not None and dist.get_backend(self.group) == "nccl":
+            file_bytes = (layout["starts"][-1] + 7) // 8
+            self.merge_seams(enc, layout)
+            image = torch.empty((file_bytes + 3) // 4 * 4, dtype=torch.uint8, device=enc.device) if self.rank == 0 else None
+            self.lib_group.gather(enc, image, 0)
+            return image[:file_bytes] if self.rank == 0 else None
+        data = self.gather_file(enc, layout)
+        return torch.frombuffer(bytearray(data), dtype=torch.uint8).to(enc.device) if data is not None else None
+
     def gather_file(self, enc, layout):
         """Bit-offset-adjusted concatenation on rank 0 -> bytes (None elsewhere): seams merged, then
         every rank's owned words into place -- over xGMI (RCCL send/recv) into an image on rank 0's

@@ -40,6 +40,59 @@ def uniform(n, seed, lo=0, hi=256):
     return np.random.default_rng(seed).integers(lo, hi, size=n, dtype=np.uint8 if hi <= 256 else np.uint16).astype(np.uint8)
 
 
+def enwik_like_distribution():
+    """A byte distribution shaped like a large mixed-markup corpus (the enwik configs of BASELINE.json, which do not
+    exist offline): 206 symbols -- 96 "text" symbols, Zipf-like, carrying almost all of the mass, and 110 rare ones
+    whose probabilities fall geometrically from 2^-12 to 2^-24.  Code lengths run from 3 to 24 bits or more: a
+    12-bit lookup misses the long codes, which the text-like stream (93 symbols, 17 bits) never shows."""
+    p = np.zeros(256, dtype=np.float64)
+    order = np.random.default_rng(0xE9).permutation(256)  # which byte value gets which rank (fixed)
+    common = 1.0 / np.arange(1, 97) ** 1.07
+    rare = 2.0 ** -(12.0 + np.arange(110) / 9.0)
+    p[order[:96]] = common / common.sum() * (1.0 - rare.sum())
+    p[order[96:206]] = rare
+    return p
+
+
+def _sample(p, n, seed):
+    cdf = np.cumsum(p)
+    cdf[-1] = 1.0
+    return np.searchsorted(cdf, np.random.default_rng(seed).random(n), side="right").astype(np.uint8)
+
+
+def enwik_like(n, seed):
+    return _sample(enwik_like_distribution(), n, seed)
+
+
+def from_env(var, n=None):
+    """A real corpus, if the environment names one (ET_CORPUS_SHAKESPEARE / ET_CORPUS_ENWIK8 / ET_CORPUS_ENWIK9:
+    SURVEY.md 8d) and the file exists: its bytes (the first n), else None."""
+    path = os.environ.get(var)
+    if not path or not os.path.isfile(path):
+        return None
+    return np.fromfile(path, dtype=np.uint8, count=-1 if n is None else n)
+
+
+def _sample_torch(p, n, seed, device):
+    import torch
+
+    cdf = torch.cumsum(torch.tensor(p, dtype=torch.float64, device=device), 0)
+    cdf[-1] = 2.0
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    step = 1 << 26
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        u = torch.rand(m, generator=g, device=device, dtype=torch.float64)  # (float32 cannot resolve 2^-24)
+        out[s : s + m] = torch.searchsorted(cdf, u, right=True).clamp_(max=255).to(torch.uint8)
+    return out
+
+
+def enwik_like_torch(n, seed, device):
+    return _sample_torch(enwik_like_distribution(), n, seed, device)
+
+
 def text_like_torch(n, seed, device):
     """Same distribution generated on the device (bench sizes): torch.multinomial-free
     inverse-CDF sampling with a seeded torch generator."""

@@ -430,15 +430,26 @@ def test_heavily_skewed_streams(ctx, p_common):
     _roundtrip(ctx, data)
 
 
-@pytest.mark.parametrize("config", ["2-text-5M", "3-text-100M"])
+@pytest.mark.parametrize("config", ["2-text-5M", "3-text-100M", "3-enwik-like-100M"])
 def test_baseline_configs_bit_exact(ctx, config):
     """BASELINE.json configs 2 and 3 at their full sizes (the corpora do not exist
     offline, so Midsummer tiled to 5 458 199 B and 10^8 order-0 samples of its distribution,
-    seed 0x5EED0003): the GPU .et image is the oracle's, byte for byte, and decodes back.
-    (Config 1 is test_reference_fixtures, config 4 the bench and
-    test_large_stream_properties, config 5 tests/config5_check.py.)"""
+    seed 0x5EED0003 -- or the real files when $ET_CORPUS_SHAKESPEARE / $ET_CORPUS_ENWIK8 name them):
+    the GPU .et image is the oracle's, byte for byte, and decodes back.  "enwik-like": 10^8 bytes
+    of the 206-symbol stream with code lengths up to 24 (the long codes enwik has and text has not).
+    (Config 1 is test_reference_fixtures, config 4 test_gpu_configs.py::test_text_1gib_image_is_byte_exact
+    and the bench, config 5 test_gpu_configs.py::test_config5_*.)"""
     O = _oracle()
-    data = corpus.tiled_midsummer(5_458_199) if config.startswith("2") else corpus.text_like(100_000_000, 0x5EED0003)
+    if config.startswith("2"):
+        data = corpus.from_env("ET_CORPUS_SHAKESPEARE")
+        data = corpus.tiled_midsummer(5_458_199) if data is None else data
+    elif config == "3-text-100M":
+        data = corpus.from_env("ET_CORPUS_ENWIK8")
+        data = corpus.text_like(100_000_000, 0x5EED0003) if data is None else data
+    else:
+        data = corpus.enwik_like(100_000_000, 0x5EED0008)
+        _, ol, _ = O.build_dict(O.histogram(data))
+        assert int((ol > 0).sum()) >= 200 and int(ol.max()) >= 20
     want = O.encode(data)
     got = ctx.encode(data)
     assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
