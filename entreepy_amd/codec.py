@@ -187,7 +187,8 @@ class Context:
         else:
             _check(N.lib().et_last_timings_of(self._h, {"encode": 0, "decode": 1}[which], ctypes.byref(t)), self._h)
         d = {k: getattr(t, k) for k, _ in N.Timings._fields_ if k not in ("reserved", "pad_")}
-        d["exhaustive_sync"] = bool(t.reserved)
+        d["exhaustive_sync"] = bool(t.reserved & 1)
+        d["tree_walk_sync"] = bool(t.reserved & 2)
         return d
 
     def last_codebook(self):

@@ -829,6 +829,44 @@ extern "C" int et_selftest_decode_tables(et_ctx *ctx, const et_codebook *cb, int
     return *where ? fail(ctx, ET_ERR_FORMAT, "device-built decode tables differ from the host builders'") : ET_OK;
 }
 
+extern "C" int et_selftest_treewalk_table(et_ctx *ctx, const et_codebook *cb, uint32_t *first_diff) {
+    if (!ctx || !cb || !first_diff) return ET_ERR_ARG;
+    *first_diff = 0;
+    DeviceGuard guard(ctx->device);
+    et::TwTree *tree = ctx->h_tw_tree[0];
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    if (et::tw_build_tree(cb, tree) != ET_OK) return fail(ctx, ET_ERR_UNSUPPORTED, "not a full code tree: the tree walk does not apply");
+    const uint32_t entries = et::tw_table_entries(tree->n_int);
+    ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
+    ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwTree)));
+    ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, tree, sizeof(et::TwTree), hipMemcpyHostToDevice, ctx->stream));
+    et::launch_tw_build(ctx->stream, static_cast<const et::TwTree *>(ctx->tw_tree.p), tree->n_int, static_cast<uint16_t *>(ctx->tw_table.p));
+    ET_HIP(hipGetLastError());
+    std::vector<uint16_t> dev(entries), host(entries);
+    ET_HIP(hipMemcpyAsync(dev.data(), ctx->tw_table.p, entries * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipStreamSynchronize(ctx->stream));
+    et::tw_fill_table(tree, host.data());
+    for (uint32_t i = 0; i < entries; ++i)
+        if (dev[i] != host[i]) {
+            *first_diff = i + 1;
+            return fail(ctx, ET_ERR_FORMAT, "device-built tree-walk table differs from the host fill");
+        }
+    return ET_OK;
+}
+
+extern "C" int et_treewalk_table(const et_codebook *cb, uint16_t *table, size_t cap_entries, uint32_t *n_int) {
+    if (!cb || !n_int) return ET_ERR_ARG;
+    static thread_local et::TwTree tree;
+    const int rc = et::tw_build_tree(cb, &tree);
+    if (rc != ET_OK) return rc;
+    *n_int = tree.n_int;
+    if (table) {
+        if (cap_entries < et::tw_table_entries(tree.n_int)) return ET_ERR_CAP;
+        et::tw_fill_table(&tree, table);
+    }
+    return ET_OK;
+}
+
 extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body, size_t body_bytes, uint32_t start_bit,
                                      uint64_t n_symbols, void *d_out, size_t cap, size_t *out_len) {
     if (!ctx || !cb || !out_len) return ET_ERR_ARG;
@@ -1007,7 +1045,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm_dec = et_timings{};
         ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
         ctx->tm_dec.sync_iters = iters;
-        ctx->tm_dec.reserved = exhaustive ? 1u : 0u;
+        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u);
         ctx->pend_dec = true;
         ctx->pend_dec_first = iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2);
         ctx->last_kind = 1;

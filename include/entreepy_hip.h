@@ -64,7 +64,7 @@ typedef struct et_timings {
     float sync_ms;      /* decode: everything in front of the write kernel (sweeps, verification, scan) */
     float total_ms;     /* begin of the first large kernel to the end of the last */
     uint32_t sync_iters;/* decode: synchronisation launches */
-    uint32_t reserved;  /* decode: 1 when the exhaustive synchronisation path ran */
+    uint32_t reserved;  /* decode: bit 0 = the exhaustive synchronisation path ran, bit 1 = the sweeps ran as a tree walk */
     float sync_first_ms;/* decode: the first synchronisation sweep alone (k_dec_sync<first>) */
     uint32_t pad_;
 } et_timings;
@@ -153,6 +153,16 @@ int et_check_magic(const uint8_t first4[4], const char **why);
  * them entry for entry.  ET_OK when identical; ET_ERR_FORMAT with *where = 1 first-level table,
  * 2 long list, 3 second-level tables, 4 code lengths, 5 step table, 6 write-step table. */
 int et_selftest_decode_tables(et_ctx *ctx, const et_codebook *cb, int *where);
+
+/* The synchronisation sweeps of a decode run as a fixed-rate walk over the code TREE when the dictionary is a
+ * full binary tree (an encoder's always is): one table row per internal node, one byte of the stream per step
+ * (csrc/et_treewalk.h).  et_treewalk_table: that table as the host fills it -- (*n_int + 7) x 256 entries of
+ * next row | codewords completed in the byte << 9 | bit at which the first of them ends << 13 -- or
+ * ET_ERR_UNSUPPORTED when the walk does not apply (table may be NULL to ask just that).
+ * et_selftest_treewalk_table: build it on the device (what a decode does) and compare it with the host fill;
+ * *first_diff = 1 + the first differing entry. */
+int et_treewalk_table(const et_codebook *cb, uint16_t *table, size_t cap_entries, uint32_t *n_int);
+int et_selftest_treewalk_table(et_ctx *ctx, const et_codebook *cb, uint32_t *first_diff);
 
 /* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */
 int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols);

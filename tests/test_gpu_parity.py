@@ -705,3 +705,57 @@ def test_declared_length_shorter_or_longer_than_the_body(ctx):
         want = O.decode(bytes(et), cap=max(n_decl, 900_000) + 64)
         assert min(n_decl, 900_000) <= len(want) <= min(n_decl, 900_002)  # (pad bits may hold one more short code)
         assert ctx.decode(bytes(et)) == want, f"declared {n_decl}"
+
+
+def test_tree_walk_sync_is_what_a_decode_runs(ctx):
+    """The synchronisation sweeps of an ordinary decode are the tree walk (et_treewalk.hip): timings say so, the
+    table the device builds equals the host fill, and streams built to stress it -- every code length from 1 to
+    24, a known first bit at every offset of a word, stream ends at every byte of a 512-bit lane -- decode to
+    what the oracle decodes."""
+    import ctypes
+
+    import torch
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+
+    O = _oracle()
+    ctx.enable_timing(True)
+    try:
+        data = corpus.text_like(3_000_000, 99)
+        et = O.encode(data)
+        comp = torch.frombuffer(bytearray(et[4:]), dtype=torch.uint8).cuda()
+        out = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+        assert ctx.decode_device(comp, out) == data.size
+        t = ctx.timings("decode")
+        assert t["tree_walk_sync"] and not t["exhaustive_sync"]
+        assert out[: data.size].cpu().numpy().tobytes() == data.tobytes()
+    finally:
+        ctx.enable_timing(False)
+    # device-built table == host fill, for code tables of many shapes
+    rng = np.random.default_rng(12)
+    for trial in range(25):
+        k = int(rng.integers(2, 257))
+        h = np.zeros(256, dtype=np.uint64)
+        h[rng.choice(256, size=k, replace=False)] = rng.integers(1, 1 << int(rng.integers(2, 28)), size=k)
+        cb = E.Codebook.from_histogram(h)
+        if cb.raw.max_length > 32:
+            continue
+        diff = ctypes.c_uint32(0)
+        assert N.lib().et_selftest_treewalk_table(ctx._h, ctypes.byref(cb.raw), ctypes.byref(diff)) == N.ET_OK, diff.value
+    # geometric counts: code lengths 1 .. 24; lengths of the stream that end it at every byte of a lane
+    sym = np.repeat(np.arange(25, dtype=np.uint8) + 60, np.maximum(1, (1 << 24) >> np.arange(25)))
+    rng.shuffle(sym)
+    for cut in list(range(0, 70)) + [8191, 8192, 8193]:
+        piece = sym[: sym.size - cut * 3]
+        et = O.encode(piece)
+        assert ctx.decode(et[4:]) == piece.tobytes(), cut
+    # the body's first bit at every offset of a 4-byte word: slices of a device buffer at different alignments
+    et = O.encode(corpus.text_like(400_000, 100))
+    want = O.decode(et[4:])
+    for shift in range(8):
+        buf = torch.zeros(len(et) + 16, dtype=torch.uint8, device="cuda")
+        buf[shift : shift + len(et) - 4] = torch.frombuffer(bytearray(et[4:]), dtype=torch.uint8).cuda()
+        out = torch.empty(400_064, dtype=torch.uint8, device="cuda")
+        m = ctx.decode_device(buf[shift : shift + len(et) - 4], out)
+        assert out[:m].cpu().numpy().tobytes() == want, shift

@@ -236,3 +236,69 @@ def test_prefix_collision_check_follows_the_reference_loop():
         assert got == reference_loop(d, l)
         hits += len(got)
     assert (65, 66) in reference_loop(*tables[0]) and hits > 2
+
+
+def _brute_treewalk_table(data, length):
+    """(row, byte) -> next row | completions << 9 | bit of the first << 13, from the codes alone: rows are the
+    proper prefixes of the codes, numbered in the order the library meets them (symbols ascending, bits from
+    the first), then 7 entry rows "skip b bits, then from the root"."""
+    rows = {(): 0}
+    codes = {}
+    for s in range(256):
+        if length[s]:
+            bits = tuple((int(data[s]) >> i) & 1 for i in range(int(length[s]) - 1, -1, -1))
+            codes[bits] = s
+            for k in range(1, len(bits)):
+                rows.setdefault(bits[:k], len(rows))
+    n_int = len(rows)
+    prefix_of = {v: k for k, v in rows.items()}
+    table = np.zeros((n_int + 7) * 256, dtype=np.uint16)
+    for r in range(n_int + 7):
+        for f in range(256):
+            cur = prefix_of[r] if r < n_int else ()
+            skip = 0 if r < n_int else r - n_int + 1
+            n = first = 0
+            for i in range(skip, 8):
+                cur = cur + ((f >> (7 - i)) & 1,)
+                if cur in codes:
+                    if n == 0:
+                        first = i
+                    n += 1
+                    cur = ()
+            table[r * 256 + f] = rows[cur] | (n << 9) | (first << 13)
+    return n_int, table
+
+
+def test_treewalk_table_against_brute_force():
+    """et_treewalk_table (tw_build_tree + tw_fill_table, the reference the device-built table is compared with on
+    the GPU) equals a table derived from the codes by brute force, for code tables of the product's own
+    construction; dictionaries that are not full trees are turned away."""
+    import ctypes
+
+    from entreepy_amd import _native as N
+    from entreepy_amd.codec import Codebook
+
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        k = int(rng.integers(2, 257)) if trial else 256
+        h = np.zeros(256, dtype=np.uint64)
+        h[rng.choice(256, size=k, replace=False)] = rng.integers(1, 1 << int(rng.integers(2, 30)), size=k)
+        cb = Codebook.from_histogram(h)
+        if cb.raw.max_length > 32:
+            continue
+        n_int = ctypes.c_uint32(0)
+        cap = (256 + 7) * 256
+        table = np.zeros(cap, dtype=np.uint16)
+        rc = N.lib().et_treewalk_table(ctypes.byref(cb.raw), table.ctypes.data, cap, ctypes.byref(n_int))
+        assert rc == N.ET_OK
+        want_n, want = _brute_treewalk_table(cb.data, cb.length)
+        assert n_int.value == want_n == cb.raw.n_coded - 1
+        assert np.array_equal(table[: want.size], want)
+    # one symbol: no tree; a prefix-free set that is not a full tree: not for the walk
+    one = Codebook.from_tables(np.zeros(256, dtype=np.uint32), np.zeros(256, dtype=np.uint8))
+    n_int = ctypes.c_uint32(0)
+    assert N.lib().et_treewalk_table(ctypes.byref(one.raw), None, 0, ctypes.byref(n_int)) == N.ET_ERR_UNSUPPORTED
+    d, l = np.zeros(256, dtype=np.uint32), np.zeros(256, dtype=np.uint8)
+    d[65], l[65], d[66], l[66] = 0b0, 1, 0b10, 2  # "11" is missing
+    gap = Codebook.from_tables(d, l)
+    assert N.lib().et_treewalk_table(ctypes.byref(gap.raw), None, 0, ctypes.byref(n_int)) == N.ET_ERR_UNSUPPORTED

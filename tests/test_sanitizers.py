@@ -292,3 +292,66 @@ def test_fast_cpu_variant_under_asan_ubsan(tmp_path):
     subprocess.check_call(cmd)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+TREEWALK_DRIVER = textwrap.dedent(r"""
+    #include "entreepy_hip.h"
+    #include "et_treewalk.h"
+    #include <cstdio>
+    #include <cstring>
+    #include <vector>
+    // The tree walk's host part (et_treewalk_host.cpp) against a bit-serial decoder: for code tables of the
+    // product's own construction, walking random bytes through the table from any row must end in the node,
+    // and count the codewords, that decoding the same bits one at a time does.
+    static uint64_t rng = 0x2545F4914F6CDD1Dull;
+    static uint64_t next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; }
+    int main() {
+        static et::TwTree tree;
+        std::vector<uint16_t> table((et::TW_MAX_NODES + et::TW_ENTRY_ROWS) * 256);
+        for (int it = 0; it < 300; ++it) {
+            uint64_t hist[256] = {0};
+            int k = 2 + next() % 255;
+            for (int i = 0; i < k; ++i) hist[next() % 256] = 1 + next() % (1ull << (next() % 24));
+            et_codebook cb;
+            if (et_build_codebook(hist, &cb) != ET_OK || cb.n_coded < 2 || cb.max_length > 32) continue;
+            if (et::tw_build_tree(&cb, &tree) != ET_OK) { std::puts("a Huffman table was turned away"); return 1; }
+            if (tree.n_int != cb.n_coded - 1) { std::puts("node count"); return 1; }
+            et::tw_fill_table(&tree, table.data());
+            for (int w = 0; w < 200; ++w) {
+                uint32_t row = next() % tree.n_int, node = row, count = 0, first = 99;
+                uint8_t byte = (uint8_t)next();
+                for (int i = 0; i < 8; ++i) {
+                    int16_t c = tree.child[2 * node + ((byte >> (7 - i)) & 1)];
+                    if (c >= 0) node = c; else { if (!count) first = i; ++count; node = 0; }
+                }
+                uint16_t e = table[(row << 8) + byte];
+                if ((e & et::TW_ROW_MASK) != node || ((e >> et::TW_N_SHIFT) & 15u) != count || (count && (uint32_t)(e >> et::TW_OFF_SHIFT) != first)) {
+                    std::puts("entry mismatch");
+                    return 1;
+                }
+            }
+        }
+        // dictionaries that are not full trees (or not prefix-free) are turned away, never walked
+        et_codebook bad;
+        std::memset(&bad, 0, sizeof bad);
+        bad.length[1] = 1; bad.data[1] = 0; bad.length[2] = 2; bad.data[2] = 2; bad.n_coded = 2; bad.min_length = 1; bad.max_length = 2;
+        if (et::tw_build_tree(&bad, &tree) == ET_OK) { std::puts("a gap was accepted"); return 1; }
+        bad.length[3] = 2; bad.data[3] = 1; bad.n_coded = 3;  // "01" under the leaf "0"
+        if (et::tw_build_tree(&bad, &tree) == ET_OK) { std::puts("a prefix clash was accepted"); return 1; }
+        std::printf("ok\n");
+        return 0;
+    }
+""")
+
+
+@pytest.mark.skipif(subprocess.run(["which", "g++"], capture_output=True).returncode != 0, reason="g++ missing")
+def test_treewalk_host_part_under_asan_ubsan(tmp_path):
+    src = tmp_path / "tw.cpp"
+    src.write_text(TREEWALK_DRIVER)
+    exe = tmp_path / "tw"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           f"-I{ROOT}/include", f"-I{ROOT}/entreepy_amd/csrc", str(src), f"{ROOT}/entreepy_amd/csrc/et_treewalk_host.cpp",
+           f"{ROOT}/entreepy_amd/csrc/et_codebook.cpp", "-o", str(exe)]
+    subprocess.check_call(cmd)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
