@@ -3,8 +3,8 @@
 
 A "step" is one pass of the hot path over one batch: encode the rank's text stream
 to a .et image (K1 histogram -> host code construction -> K2 scan -> K4 scatter) and
-decode that image back (D1 sync sweeps -> D2 scan -> D3 write), inputs resident in
-HBM.  Workload at N=1 (BASELINE.json metric): "text-1G", 2^30 bytes of order-0
+decode that image back (D1 synchronisation by tree walk -> D2 scan -> D3 write), inputs
+resident in HBM.  Workload at N=1 (BASELINE.json metric): "text-1G", 2^30 bytes of order-0
 samples of res/a_midsummer_nights_dream.txt's byte distribution (no benchmark corpus
 exists offline).  N>1: every rank holds its own 2^30-byte shard of one
 N-GiB stream (weak scaling); the shards share one code table through an RCCL
@@ -280,7 +280,7 @@ def main():
             # that dispatch, no marker packets), recorded in every step of the timed region.
             "k_hist_tiles": (ms["hist"], n),
             "k_encode_tiles": (ms["enc_body"], n + m_bytes),
-            "k_dec_sync_reg2": (ms["dec_sync_first"], m_bytes),
+            "k_tw_sync": (ms["dec_sync_first"], m_bytes),
             "k_dec_write_reg": (ms["dec_body"], m_bytes + n),
         }
         dominant = max(kernels, key=lambda k: kernels[k][0])
