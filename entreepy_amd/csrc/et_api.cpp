@@ -59,8 +59,8 @@ struct et_ctx {
     // decode workspaces
     DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag, worklist;  // flag: [0..3] sweep flags, [4] ticket, [8..] worklist counts  // lut: all decode tables, DEC_TABLES_BYTES
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
-    DevBuf tw_table, tw_tree, blk_start;                   // tree-walk synchronisation (et_treewalk.h)
-    et::TwTree *h_tw_tree[2] = {};                         // pinned, used in turn like h_lut_buf
+    DevBuf tw_table, tw_tree, blk_start, chain_table;      // tree-walk synchronisation, chained write tables (et_treewalk.h)
+    et::TwUpload *h_tw_tree[2] = {};                       // pinned, used in turn like h_lut_buf
     // staging for the host-pointer / file-descriptor entry points
     DevBuf io_in, io_out;
     et_io::Pipe *io = nullptr;  // pinned double buffer + copy threads, made on first use
@@ -322,7 +322,7 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     }
     ctx->h_lut = ctx->h_lut_buf[0];
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 16 * sizeof(uint64_t)) == hipSuccess;
-    for (int i = 0; i < 2; ++i) ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tw_tree[i]), sizeof(et::TwTree)) == hipSuccess;
+    for (int i = 0; i < 2; ++i) ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tw_tree[i]), sizeof(et::TwUpload)) == hipSuccess;
     // timing-only events: no system-scope fence when they complete (hip_runtime_api.h: "for events that
     // are only being used to measure timing"); with the default flags the ten records of an
     // encode+decode cost ~65 us of cache write-backs and waits at 1 GiB
@@ -343,7 +343,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->group_sum,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->flag,
                       &ctx->worklist, &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
-                      &ctx->tw_table, &ctx->tw_tree, &ctx->blk_start, &ctx->io_in, &ctx->io_out};
+                      &ctx->tw_table, &ctx->tw_tree, &ctx->blk_start, &ctx->chain_table, &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     delete ctx->io;
@@ -446,7 +446,8 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
     ET_TRY(ensure(ctx, ctx->lut, DEC_TABLES_BYTES));
     ET_TRY(ensure(ctx, ctx->flag, 64));
     ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
-    ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwTree)));
+    ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwUpload)));
+    ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
     ET_TRY(ensure(ctx, ctx->blk_start, n_blocks * sizeof(uint32_t)));
     return ET_OK;
 }
@@ -833,23 +834,35 @@ extern "C" int et_selftest_treewalk_table(et_ctx *ctx, const et_codebook *cb, ui
     if (!ctx || !cb || !first_diff) return ET_ERR_ARG;
     *first_diff = 0;
     DeviceGuard guard(ctx->device);
-    et::TwTree *tree = ctx->h_tw_tree[0];
+    et::TwUpload *up = ctx->h_tw_tree[0];
+    et::TwTree *tree = &up->tree;
     ET_HIP(hipStreamSynchronize(ctx->stream));
     if (et::tw_build_tree(cb, tree) != ET_OK) return fail(ctx, ET_ERR_UNSUPPORTED, "not a full code tree: the tree walk does not apply");
-    const uint32_t entries = et::tw_table_entries(tree->n_int);
+    et::tw_chain_plan(tree, &up->plan);
+    const uint32_t entries = et::tw_table_entries(tree->n_int), n_chain = up->plan.n_entries;
     ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
-    ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwTree)));
-    ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, tree, sizeof(et::TwTree), hipMemcpyHostToDevice, ctx->stream));
-    et::launch_tw_build(ctx->stream, static_cast<const et::TwTree *>(ctx->tw_tree.p), tree->n_int, static_cast<uint16_t *>(ctx->tw_table.p));
+    ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwUpload)));
+    ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
+    ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, up, et::tw_upload_bytes(up), hipMemcpyHostToDevice, ctx->stream));
+    et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), tree->n_int, static_cast<uint16_t *>(ctx->tw_table.p), n_chain,
+                        static_cast<uint64_t *>(ctx->chain_table.p));
     ET_HIP(hipGetLastError());
     std::vector<uint16_t> dev(entries), host(entries);
+    std::vector<uint64_t> dev_chain(n_chain), host_chain(n_chain);
     ET_HIP(hipMemcpyAsync(dev.data(), ctx->tw_table.p, entries * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+    ET_HIP(hipMemcpyAsync(dev_chain.data(), ctx->chain_table.p, n_chain * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     ET_HIP(hipStreamSynchronize(ctx->stream));
     et::tw_fill_table(tree, host.data());
+    et::tw_chain_fill(tree, &up->plan, host_chain.data());
     for (uint32_t i = 0; i < entries; ++i)
         if (dev[i] != host[i]) {
             *first_diff = i + 1;
             return fail(ctx, ET_ERR_FORMAT, "device-built tree-walk table differs from the host fill");
+        }
+    for (uint32_t i = 0; i < n_chain; ++i)
+        if (dev_chain[i] != host_chain[i]) {
+            *first_diff = entries + i + 1;
+            return fail(ctx, ET_ERR_FORMAT, "device-built chained write tables differ from the host fill");
         }
     return ET_OK;
 }
@@ -863,6 +876,29 @@ extern "C" int et_treewalk_table(const et_codebook *cb, uint16_t *table, size_t 
     if (table) {
         if (cap_entries < et::tw_table_entries(tree.n_int)) return ET_ERR_CAP;
         et::tw_fill_table(&tree, table);
+    }
+    return ET_OK;
+}
+
+extern "C" int et_chain_tables(const et_codebook *cb, uint64_t *table, size_t cap_entries, uint32_t *n_entries, uint32_t *table_first, uint8_t *table_bits,
+                               size_t cap_tables, uint32_t *n_tables) {
+    if (!cb || !n_entries || !n_tables) return ET_ERR_ARG;
+    static thread_local et::TwUpload up;
+    const int rc = et::tw_build_tree(cb, &up.tree);
+    if (rc != ET_OK) return rc;
+    et::tw_chain_plan(&up.tree, &up.plan);
+    *n_entries = up.plan.n_entries;
+    *n_tables = up.plan.n_tables;
+    if (table) {
+        if (cap_entries < up.plan.n_entries) return ET_ERR_CAP;
+        et::tw_chain_fill(&up.tree, &up.plan, table);
+    }
+    if (table_first && table_bits) {
+        if (cap_tables < up.plan.n_tables) return ET_ERR_CAP;
+        for (uint32_t t = 0; t < up.plan.n_tables; ++t) {
+            table_first[t] = up.plan.tab[t].first;
+            table_bits[t] = up.plan.tab[t].bits;
+        }
     }
     return ET_OK;
 }
@@ -924,6 +960,10 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 4);  // host copy of flag[0..15]
     const bool can_speculate = cap >= n_symbols;
     bool wrote = false, write_ticket_zero = false;
+    uint32_t *blk_start = nullptr;        // tree-walk sweeps (below)
+    const uint16_t *tw_table = nullptr;
+    const uint64_t *chain = nullptr;      // chained write tables (below)
+    uint32_t tw_n_int = 0, n_chain = 0;
     auto scan_and_total = [&](bool verify) -> int {
         // (the scan's last thread stores the flags and the total straight into the pinned h_flags)
         et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
@@ -935,7 +975,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
         // speculative: the kernel itself looks at the sweeps' flags and does nothing if the state is not final
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
-                             write_ticket_zero, speculative ? flag : nullptr, timed(ctx, EV_DEC + 2, EV_DEC + 3));
+                             write_ticket_zero, speculative ? flag : nullptr, timed(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain);
         write_ticket_zero = false;
         ET_HIP(hipGetLastError());
         return ET_OK;
@@ -945,20 +985,28 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     bool more_sweeps = false;
     // The synchronisation sweeps by tree walk (et_treewalk.h) when the code table is a full tree -- an
     // encoder's always is -- and the stream is more than a few blocks; the register-window sweeps otherwise.
-    uint32_t *blk_start = nullptr;
-    const uint16_t *tw_table = nullptr;
-    uint32_t tw_n_int = 0;
-    if (!exhaustive && n_blocks >= 16) {
-        et::TwTree *h_tree = ctx->h_tw_tree[ctx->lut_turn];  // (prepare_decode_tables has just flipped the turn: this one is free)
-        if (et::tw_build_tree(cb, h_tree) == ET_OK) {
-            ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
-            ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwTree)));
-            ET_TRY(ensure(ctx, ctx->blk_start, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
-            tw_n_int = h_tree->n_int;
-            ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, h_tree, 8 + 4 * static_cast<size_t>(tw_n_int), hipMemcpyHostToDevice, ctx->stream));
-            et::launch_tw_build(ctx->stream, static_cast<const et::TwTree *>(ctx->tw_tree.p), tw_n_int, static_cast<uint16_t *>(ctx->tw_table.p));
-            tw_table = static_cast<const uint16_t *>(ctx->tw_table.p);
-            blk_start = static_cast<uint32_t *>(ctx->blk_start.p);
+    // The write walk over chained lookup tables (no escapes) under the same condition, whatever the sweeps are.
+    if (n_blocks > 3) {
+        et::TwUpload *h_up = ctx->h_tw_tree[ctx->lut_turn];  // (prepare_decode_tables has just flipped the turn: this one is free)
+        if (et::tw_build_tree(cb, &h_up->tree) == ET_OK) {
+            et::tw_chain_plan(&h_up->tree, &h_up->plan);
+            const bool sweeps = !exhaustive && n_blocks >= 16;
+            ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwUpload)));
+            ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
+            if (sweeps) {
+                ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
+                ET_TRY(ensure(ctx, ctx->blk_start, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            }
+            tw_n_int = h_up->tree.n_int;
+            n_chain = h_up->plan.n_entries;
+            ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, h_up, et::tw_upload_bytes(h_up), hipMemcpyHostToDevice, ctx->stream));
+            et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), tw_n_int, sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr,
+                                n_chain, static_cast<uint64_t *>(ctx->chain_table.p));
+            chain = static_cast<const uint64_t *>(ctx->chain_table.p);
+            if (sweeps) {
+                tw_table = static_cast<const uint16_t *>(ctx->tw_table.p);
+                blk_start = static_cast<uint32_t *>(ctx->blk_start.p);
+            }
         }
     }
     auto scan_and_total_tw = [&]() -> int {
@@ -1045,7 +1093,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm_dec = et_timings{};
         ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
         ctx->tm_dec.sync_iters = iters;
-        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u);
+        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u);
         ctx->pend_dec = true;
         ctx->pend_dec_first = iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2);
         ctx->last_kind = 1;

@@ -104,6 +104,7 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr,
-                      bool ticket_is_zero = false, const uint32_t *void_flags = nullptr, KernelEvents ev = {});  // ev: the main write kernel
+                      bool ticket_is_zero = false, const uint32_t *void_flags = nullptr, KernelEvents ev = {},  // ev: the main write kernel
+                      const uint64_t *chain = nullptr, uint32_t n_chain = 0);  // chained lookup tables (et_treewalk.h): interior blocks by k_dec_write_chain
 
 }  // namespace et

@@ -19,6 +19,7 @@
 // coalesced; a "tile" is 1..16 consecutive rounds and is the unit for which K1
 // leaves a 256-bin histogram and K4 gets a start bit offset.
 #include "et_kernels.h"
+#include "et_treewalk.h"
 
 #include <hip/hip_ext.h>
 
@@ -1870,6 +1871,236 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// D3 over chained lookup tables (et_treewalk.h): the same greedy register-window walk, but the table entry names the
+// table of the next lookup, so a code longer than the index is one more lockstep step of ITS lane instead of an
+// escape that stops the wavefront.  State: X = (stage position << 10) | G as in walk_write, H = the hi dword of
+// the last entry (next table's LDS address, second symbol, next shift).
+struct ChainWalk {
+    uint32_t root_h;  // H at a codeword boundary: the root table's LDS address | (32 - CH_ROOT_BITS) << 24
+    uint32_t root_t;  // its address alone
+};
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+
+// MODE 1: positions are LDS addresses - 1 (the whole block fits the stage).  Words whose positions lie 64 or more
+// bits before the subsequence's end use the FAST step: both symbol bytes stored behind one another, whatever the
+// entry holds.  After a one-symbol entry the second slot holds a stray byte, after a no-symbol entry both do -- the
+// lane's own slots: a codeword that BEGINS there is at most 32 bits long, so it ends before the subsequence does,
+// another codeword of this lane begins behind it, and its store (stores of one wavefront reach the LDS in program
+// order) lands on the stray byte.  From there on the SAFE step, which touches nothing but the slots of the symbols
+// the entry completes (the slot behind a lane's LAST symbol is the next lane's first, written long before).
+// MODE 2: positions are indices into the block's output; bytes in [lo, hi) go to stage[pos - lo] (blocks that
+// overflow the stage or the declared symbol count: conditional stores throughout).
+template <int MODE>
+__device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *smem8, const uint32_t (&W)[RW_WORDS], uint32_t start_rel, uint32_t pos0,
+                                                 uint32_t lo, uint32_t hi, uint32_t stage_off) {
+    uint32_t X = (pos0 << 10) | (64 - start_rel), H = cw.root_h;
+    uint2 e;
+#define CH_G (X & 1023u)
+#define CH_MID ((H & 0xffffu) != cw.root_t)
+#define CH_READ(hi_, lo_)                                                                                        \
+    {                                                                                                            \
+        const uint32_t w_ = __builtin_amdgcn_alignbit(hi_, lo_, X);                                              \
+        const unsigned long long v_ = *reinterpret_cast<const lds_u64 *>(static_cast<uintptr_t>(((w_ >> (H >> 24)) << 3) + (H & 0xffffu))); \
+        e.x = static_cast<uint32_t>(v_);                                                                         \
+        e.y = static_cast<uint32_t>(v_ >> 32);                                                                   \
+    }
+#define CH_ADV X += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(e.x)))
+#define CH_PUT1(slot_, v_) *reinterpret_cast<lds_u8 *>(static_cast<uintptr_t>((slot_) + 1u)) = static_cast<uint8_t>(v_)
+#define CH_PUT2(slot_, v_)                                                                   \
+    {                                                                                        \
+        const uint32_t q_ = (slot_);                                                         \
+        if (q_ - lo < hi - lo) smem8[stage_off + (q_ - lo)] = static_cast<uint8_t>(v_);       \
+    }
+#define CH_STEP_FAST(hi_, lo_)           \
+    {                                    \
+        CH_READ(hi_, lo_)                \
+        H = e.y;                         \
+        const uint32_t p0_ = X >> 10;    \
+        CH_ADV;                          \
+        CH_PUT1(p0_, e.x >> 16);         \
+        CH_PUT1(p0_ + 1u, e.y >> 16);    \
+    }
+#define CH_STEP_SAFE(hi_, lo_)                                                              \
+    {                                                                                       \
+        CH_READ(hi_, lo_)                                                                   \
+        H = e.y;                                                                            \
+        const uint32_t p0_ = X >> 10;                                                       \
+        CH_ADV;                                                                             \
+        const uint32_t p1_ = X >> 10;                                                       \
+        if (MODE == 1) {                                                                    \
+            /* second symbol first: at p0 + 1 for two symbols, else at p0, where the first (or, for none, a later one) overwrites it */ \
+            CH_PUT1(p1_ - 1u + (p1_ == p0_ ? 1u : 0u), e.y >> 16);                          \
+            CH_PUT1(p0_, e.x >> 16);                                                        \
+        } else {                                                                            \
+            if (p1_ != p0_) CH_PUT2(p0_, e.x >> 16)                                         \
+            if (p1_ - p0_ == 2u) CH_PUT2(p0_ + 1u, e.y >> 16)                               \
+        }                                                                                   \
+    }
+// one codeword (or one more table of it) at a time
+#define CH_STEP_ONE(hi_, lo_)                        \
+    {                                                \
+        CH_READ(hi_, lo_)                            \
+        const uint32_t lf_ = e.x >> 24;              \
+        if (lf_) {                                   \
+            if (MODE == 1) CH_PUT1(X >> 10, e.x >> 16); \
+            else CH_PUT2(X >> 10, e.x >> 16)         \
+            X += (1u << 10) - lf_;                   \
+            H = cw.root_h;                           \
+        } else {                                     \
+            CH_ADV;                                  \
+            H = e.y;                                 \
+        }                                            \
+    }
+#define CH_WORD_FAST(hi_, lo_)                        \
+    while (CH_G >= 64u) {                             \
+        if (MODE == 1) CH_STEP_FAST(hi_, lo_)         \
+        else CH_STEP_SAFE(hi_, lo_)                   \
+    }                                                 \
+    X += 32;
+    CH_WORD_FAST(W[3], W[4])  // only lanes that start at bit 0
+    CH_WORD_FAST(W[4], W[5])
+    CH_WORD_FAST(W[5], W[6])
+    CH_WORD_FAST(W[6], W[7])
+    CH_WORD_FAST(W[7], W[8])
+    CH_WORD_FAST(W[8], W[9])
+    CH_WORD_FAST(W[9], W[10])
+    while (CH_G >= 64u) CH_STEP_SAFE(W[10], W[11])  // positions 193..224: a 32-bit code from 224 is the lane's last
+    X += 32;
+    // the last word: whole-index steps while the lookup's index bits all lie inside the subsequence, then one codeword at a time
+    while (CH_G + (H >> 24) >= 96u) CH_STEP_SAFE(W[11], W[12])
+    for (uint32_t k = 0; k < 40 && (CH_G > 64u || (CH_G == 64u && CH_MID)); ++k) CH_STEP_ONE(W[11], W[12])
+    // a codeword that began inside the subsequence and is still open behind it: its remaining tables
+    if (CH_MID) {
+        X += 32;
+        for (uint32_t k = 0; k < 40 && CH_MID; ++k) CH_STEP_ONE(W[12], 0u)
+    }
+#undef CH_WORD_FAST
+#undef CH_STEP_ONE
+#undef CH_STEP_SAFE
+#undef CH_STEP_FAST
+#undef CH_PUT2
+#undef CH_PUT1
+#undef CH_ADV
+#undef CH_READ
+#undef CH_MID
+#undef CH_G
+}
+
+// HALVES x 256 threads: every 256 take one 8 KiB block (as k_dec_write_reg's workgroup does) and share the tables --
+// 16 KiB for the root alone, which one block's stage beside it would hold a CU to 4 workgroups of 4 wavefronts.
+template <int HALVES>
+__global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+                                                                   const uint2 *__restrict__ chain, uint32_t n_entries,
+                                                                   const uint32_t *__restrict__ sub_state, const unsigned long long *__restrict__ blk_off,
+                                                                   uint64_t n_symbols, uint8_t *__restrict__ out, uint32_t *__restrict__ ticket,
+                                                                   const uint32_t *__restrict__ void_flags) {
+    if (void_flags && !dec_state_final(void_flags[1], void_flags[2], n_blocks)) return;  // see k_dec_write_reg
+    // LDS: tables | wave totals [2][HALVES][4], ticket | HALVES stages
+    uint2 *tab = reinterpret_cast<uint2 *>(dec_smem_raw);
+    const uint32_t tab_bytes = (n_entries * 8u + 15u) & ~15u;
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(dec_smem_raw + tab_bytes);
+    constexpr uint32_t SCRATCH_WORDS = 2 * HALVES * 4 + 4;
+    const int tid = threadIdx.x, half = tid / BLOCK, htid = tid % BLOCK, wave = htid >> 6;
+    const uint32_t stage_off = tab_bytes + SCRATCH_WORDS * 4 + half * (DEC_STAGE_BYTES + 16);
+    uint8_t *smem8 = reinterpret_cast<uint8_t *>(dec_smem_raw);
+    uint8_t *stage = smem8 + stage_off;
+    const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)dec_smem_raw));
+    const uint32_t lds_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)stage));
+    for (uint32_t i = tid; i < n_entries; i += BLOCK * HALVES) {
+        uint2 v = chain[i];
+        v.y += lds_tab;  // next-table offsets -> LDS addresses
+        tab[i] = v;
+    }
+    const ChainWalk cw = {lds_tab | ((32u - CH_ROOT_BITS) << 24), lds_tab};
+    uint32_t parity = 0;
+    for (;;) {
+        __syncthreads();  // tables staged (first trip); everybody is done with the ticket word and the stages
+        if (tid == 0) scratch[2 * HALVES * 4] = atomicAdd(ticket, WRITE_CHUNK);
+        __syncthreads();
+        const uint64_t b0 = scratch[2 * HALVES * 4];
+        if (b0 >= n_blocks) break;
+        const uint64_t b1 = b0 + WRITE_CHUNK < n_blocks ? b0 + WRITE_CHUNK : n_blocks;
+        for (uint64_t bb = b0; bb < b1; bb += HALVES) {
+            // every thread works out every half's plan, so that the barriers below are the same for all
+            uint64_t o0_of[HALVES];
+            bool act_of[HALVES], any = false;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                const uint64_t bh = bb + h;
+                act_of[h] = bh < b1 && !special_block(bh, n_bytes);  // first / last blocks: k_dec_write
+                o0_of[h] = act_of[h] ? blk_off[bh] : 0;
+                if (o0_of[h] >= n_symbols) act_of[h] = false;  // pad bits decoded past the declared length
+                any = any || act_of[h];
+            }
+            if (!any) continue;
+            const bool mine = act_of[half];
+            const uint64_t sub_g = (bb + half) * BLOCK + htid;
+            uint32_t start = 0, count = 0;
+            uint32_t W[RW_WORDS];
+            if (mine) {
+                const uint32_t st = sub_state[sub_g];
+                start = st & 31u;  // (a start is < 32 in a settled state; masked so that nothing else can reach the walk)
+                count = st >> 16;
+                load_window<false>(W, words, sub_g);
+            } else {
+#pragma unroll
+                for (int j = 0; j < RW_WORDS; ++j) W[j] = 0;
+            }
+            uint32_t *totals = scratch + parity * (HALVES * 4);
+            parity ^= 1u;
+            const uint32_t inc = wave_inclusive_scan(count);
+            if ((htid & 63) == 63) totals[half * 4 + wave] = inc;
+            __syncthreads();
+            uint32_t total_of[HALVES], n_win = 0;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                total_of[h] = totals[h * 4] + totals[h * 4 + 1] + totals[h * 4 + 2] + totals[h * 4 + 3];
+                uint64_t o1 = o0_of[h] + total_of[h];
+                if (o1 > n_symbols) o1 = n_symbols;
+                const uint32_t span = act_of[h] ? static_cast<uint32_t>(o0_of[h] & 15) + static_cast<uint32_t>(o1 - o0_of[h]) : 0u;
+                const uint32_t wins = (span + DEC_STAGE_BYTES - 1) / DEC_STAGE_BYTES;
+                n_win = wins > n_win ? wins : n_win;
+            }
+            uint32_t my_off = inc - count;
+            for (int w = 0; w < wave; ++w) my_off += totals[half * 4 + w];
+            const uint64_t o0 = o0_of[half];
+            const uint32_t block_total = total_of[half];
+            uint64_t o1 = o0 + block_total;
+            if (o1 > n_symbols) o1 = n_symbols;
+            const uint32_t n_out = mine ? static_cast<uint32_t>(o1 - o0) : 0u;
+            const uint32_t phase = static_cast<uint32_t>(o0 & 15);  // stage offset of the first symbol
+            const uint32_t span = mine ? phase + n_out : 0u;
+            uint8_t *out_base = out + (o0 - phase);
+            const bool one_window = phase + block_total <= DEC_STAGE_BYTES && n_out == block_total;
+            for (uint32_t wi = 0; wi < n_win; ++wi) {
+                const uint32_t win = wi * DEC_STAGE_BYTES;
+                const uint32_t win_hi = min(win + DEC_STAGE_BYTES, span);
+                if (win < span) {
+                    const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
+                    if (one_window) {
+                        if (count) walk_write_chain<1>(cw, smem8, W, start, lds_stage + my_lo - 1u, 0, 0, 0);
+                    } else if (my_lo < win_hi && my_hi > win) {
+                        walk_write_chain<2>(cw, smem8, W, start, my_lo, win, win_hi, stage_off);
+                    }
+                }
+                __syncthreads();
+                if (win < span) {
+                    const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
+                    for (uint32_t g = win + htid * 16; g < win_hi; g += BLOCK * 16) {
+                        if (g >= lo_valid && g + 16 <= win_hi) {
+                            *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(stage + (g - win));
+                        } else {
+                            for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = stage[k - win];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // D2 (scan of the workgroup symbol counts) is k_scan_local / k_scan_finish above.
 
 // D3: decode every subsequence from its synchronised start and write the symbols.
@@ -1975,7 +2206,7 @@ static bool use_reg_kernels(uint32_t n_blocks) { return n_blocks > 3; }
 // Workgroups of `kernel` a CU holds at once (occupancy query), remembered per (kernel, device, LDS size):
 // the query sits on the launch path, and kernels that share a signature (the k_encode_tiles<RING> variants,
 // k_dec_sync<first/later>, the k_dec_sync_reg variants) are different entries.
-static int resident_per_cu(const void *kernel, size_t smem, int *cus_out) {
+static int resident_per_cu(const void *kernel, size_t smem, int *cus_out, int threads = BLOCK) {
     struct Entry {
         const void *kernel;
         size_t smem;
@@ -1992,7 +2223,7 @@ static int resident_per_cu(const void *kernel, size_t smem, int *cus_out) {
         }
     int cus = 256, per_cu = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, smem) != hipSuccess) per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, smem) != hipSuccess) per_cu = 0;
     if (n_cached < 24) cache[n_cached++] = Entry{kernel, smem, dev, cus, per_cu};
     *cus_out = cus;
     return per_cu;
@@ -2178,10 +2409,10 @@ void launch_build_dec_tables(hipStream_t stream, const TablePlan *d_plan, uint32
 // Grid of a chunked decode kernel: one workgroup per chunk, or -- ticketed -- as many
 // workgroups as the occupancy API reports resident (an over-estimate is harmless).
 template <typename K>
-static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticketed) {
+static uint32_t decode_grid(K kernel, size_t smem, uint32_t n_chunks, bool ticketed, int threads = BLOCK) {
     if (!ticketed) return n_chunks;
     int cus = 256;
-    int per_cu = resident_per_cu(reinterpret_cast<const void *>(kernel), smem, &cus);
+    int per_cu = resident_per_cu(reinterpret_cast<const void *>(kernel), smem, &cus, threads);
     if (per_cu < 1) per_cu = 1;
     const uint32_t g = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
     return n_chunks < g ? (n_chunks ? n_chunks : 1) : g;
@@ -2304,7 +2535,7 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero,
-                      const uint32_t *void_flags, KernelEvents ev) {
+                      const uint32_t *void_flags, KernelEvents ev, const uint64_t *chain, uint32_t n_chain) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
     const size_t smem = decode_smem_bytes(tb, true, false);
@@ -2312,6 +2543,11 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     if (use_reg_kernels(n_blocks)) {
         const size_t smem_reg = (step_table_words(tb) + 64 + 8) * sizeof(uint32_t) + DEC_STAGE_BYTES + 16;
         fork_mark(side, stream);
+        if (chain) {
+            constexpr int HALVES = 2;
+            const size_t smem_chain = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + (2 * HALVES * 4 + 4) * sizeof(uint32_t) + HALVES * (DEC_STAGE_BYTES + 16);
+            ET_LAUNCH_TIMED(k_dec_write_chain<HALVES>, dim3(decode_grid(k_dec_write_chain<HALVES>, smem_chain, n_chunks, true, BLOCK * HALVES)), dim3(BLOCK * HALVES), smem_chain, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, ticket, void_flags);
+        } else
         ET_LAUNCH_TIMED(k_dec_write_reg, dim3(decode_grid(k_dec_write_reg, smem_reg, n_chunks, true)), dim3(BLOCK), smem_reg, stream, ev, words, n_bytes, n_blocks, step_table_args(tb), tb.sym_len, sub_state, blk_off, n_symbols, out, ticket, void_flags);
         const hipStream_t special = fork_special(side, stream);
         hipLaunchKernelGGL(k_dec_write, dim3(3), dim3(BLOCK), smem, special, words, n_bytes, n_subs, n_blocks, tb, sub_state, blk_off, n_symbols, out, ticket, 1u, void_flags);

@@ -16,6 +16,7 @@
 // No HIP in the tree part: et_treewalk_host.cpp also compiles with plain g++ (tests/test_sanitizers.py).
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "entreepy_hip.h"
@@ -50,6 +51,80 @@ void tw_fill_table(const TwTree *tree, uint16_t *table);
 ET_TW_HD inline uint32_t tw_rows(uint32_t n_int) { return n_int + TW_ENTRY_ROWS; }
 ET_TW_HD inline uint32_t tw_table_entries(uint32_t n_int) { return tw_rows(n_int) << 8; }
 
+// ---------------------------------------------------------------------------------------------------------
+// Chained lookup tables for the WRITE walk (D3, k_dec_write_chain in et_kernels.hip).  decode.zig:143-203 again:
+// the greedy walk looks up to two whole codewords up per step in a table indexed by the next CH_ROOT_BITS bits.
+// A code longer than the index used to be an "escape" that threw its lane out of the wavefront's lockstep loop;
+// on a long-tailed alphabet one wavefront step in three contains one.  Here such an index is an ordinary entry --
+// no symbol, all index bits consumed, "continue in table T with an index of s bits" -- where T is the table of
+// the tree node the bits lead to.  Every table entry names the table of the NEXT lookup (the root table after a
+// completed codeword), so a step never branches on what it found.  Entry (u64, read with one ds_read_b64):
+//   lo  [15:0]  signed 16-bit: (symbols << 10) - bits consumed, added to the walk state
+//       [23:16] first symbol          [31:24] bits up to the end of the first symbol (0: none completes here)
+//   hi  [15:0]  byte offset of the next lookup's table        [23:16] second symbol
+//       [31:24] right shift that turns a 32-bit stream window into the next lookup's index (32 - its index bits)
+constexpr uint32_t CH_ROOT_BITS = 11, CH_SUB_BITS_MAX = 9, CH_SUB_ENTRIES_MAX = 576, CH_MAX_TABLES = 256;
+// (576 sub-table entries: with the 16 KiB root and two 16 KiB stages a 512-thread workgroup stays under a third of the LDS)
+constexpr uint32_t CH_MAX_ENTRIES = (1u << CH_ROOT_BITS) + CH_SUB_ENTRIES_MAX;
+
+struct ChainTable {
+    uint16_t node;  // the tree node a lookup in this table starts from (table 0: the root)
+    uint8_t bits;   // index width
+    uint8_t pad_;
+    uint32_t first;  // index of its first entry
+};
+struct ChainPlan {
+    uint32_t n_tables, n_entries, sub_bits, pad_;
+    int16_t table_of[TW_MAX_NODES];  // tree node -> its table, -1: has none
+    ChainTable tab[CH_MAX_TABLES];   // (only the first n_tables travel to the device)
+};
+// What the device needs for both tables of a code: the tree, then the plan.
+struct TwUpload {
+    TwTree tree;
+    ChainPlan plan;
+};
+inline size_t tw_upload_bytes(const TwUpload *u) { return offsetof(TwUpload, plan) + offsetof(ChainPlan, tab) + u->plan.n_tables * sizeof(ChainTable); }
+
+// Which tables a tree needs: the root's, and one for every internal node that a lookup can end on without having
+// completed a codeword, as wide as the subtree below it is deep but at most sub_bits -- the largest value (<=
+// CH_SUB_BITS_MAX) for which all of them fit CH_SUB_ENTRIES_MAX entries.  Always succeeds for a tree of tw_build_tree.
+void tw_chain_plan(const TwTree *tree, ChainPlan *plan);
+
+ET_TW_HD inline uint64_t tw_chain_entry(const TwTree *tree, const ChainPlan *plan, uint32_t t, uint32_t idx) {
+    const uint32_t s = plan->tab[t].bits;
+    uint32_t node = plan->tab[t].node, used = 0, n = 0, sym1 = 0, sym2 = 0, len_first = 0, done = 0;
+    while (used < s) {
+        const int16_t c = tree->child[2 * node + ((idx >> (s - 1 - used)) & 1u)];
+        ++used;
+        if (c >= 0) {
+            node = static_cast<uint32_t>(c);
+            continue;
+        }
+        const uint32_t sym = static_cast<uint32_t>(TW_LEAF0 - c);
+        if (n == 0) {
+            sym1 = sym;
+            len_first = used;
+        } else {
+            sym2 = sym;
+        }
+        done = used;
+        node = 0;
+        if (++n == 2) break;
+    }
+    uint32_t next = 0, adv;
+    if (n == 0) {
+        next = static_cast<uint32_t>(plan->table_of[node]);
+        adv = (0u - s) & 0xffffu;
+    } else {
+        adv = (n << 10) - done;
+    }
+    const uint32_t lo = adv | (sym1 << 16) | (len_first << 24);
+    const uint32_t hi = (plan->tab[next].first * 8u) | (sym2 << 16) | ((32u - plan->tab[next].bits) << 24);
+    return lo | (static_cast<uint64_t>(hi) << 32);
+}
+// Host fill (n_entries u64): what k_tw_chain_build is tested against.
+void tw_chain_fill(const TwTree *tree, const ChainPlan *plan, uint64_t *table);
+
 }  // namespace et
 
 #ifdef __HIPCC__
@@ -57,8 +132,9 @@ ET_TW_HD inline uint32_t tw_table_entries(uint32_t n_int) { return tw_rows(n_int
 
 namespace et {
 
-// table: tw_table_entries(n_int) u16 in device memory, filled by launch_tw_build from a TwTree in device memory.
-void launch_tw_build(hipStream_t stream, const TwTree *d_tree, uint32_t n_int, uint16_t *table);
+// table: tw_table_entries(n_int) u16 in device memory (or null), chain: n_chain u64 (or null); both filled from a
+// TwUpload in device memory (tw_upload_bytes of it) by one launch.
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain);
 
 // D1 by tree walk.  Outputs as the register-window sweep's: sub_state[s] = start bit | (start bit of s + 1) << 8
 // | codewords that begin in s << 16; blk_count[b]; and, as ROWS instead of bit offsets, blk_exit[b] = the tree

@@ -48,12 +48,23 @@ __device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__
 }
 
 // ---- the table, filled on the device from the tree -------------------------------------------------
-__global__ __launch_bounds__(1024) void k_tw_build(const TwTree *__restrict__ tree, uint32_t n_int, uint16_t *__restrict__ table) {
-    __shared__ int16_t child[2 * TW_MAX_NODES];
-    for (uint32_t i = threadIdx.x; i < 2 * n_int; i += 1024) child[i] = tree->child[i];
+// One launch fills both tables of a code: the synchronisation walk's (table, may be null) and the write walk's chained
+// lookup tables (chain, may be null; tw_chain_entry is the definition, shared with the host fill).
+__global__ __launch_bounds__(1024) void k_tw_build(const TwUpload *__restrict__ up, uint32_t n_int, uint16_t *__restrict__ table, uint32_t n_chain,
+                                                   uint64_t *__restrict__ chain) {
+    __shared__ TwTree tree;
+    for (uint32_t i = threadIdx.x; i < 2 * n_int; i += 1024) tree.child[i] = up->tree.child[i];
     __syncthreads();
-    const uint32_t entries = tw_table_entries(n_int);
-    for (uint32_t idx = blockIdx.x * 1024 + threadIdx.x; idx < entries; idx += gridDim.x * 1024) {
+    const uint32_t entries = table ? tw_table_entries(n_int) : 0;
+    const int16_t *child = tree.child;
+    for (uint32_t idx = blockIdx.x * 1024 + threadIdx.x; idx < entries + n_chain; idx += gridDim.x * 1024) {
+        if (idx >= entries) {
+            const uint32_t i = idx - entries;
+            uint32_t t = 0;
+            while (t + 1 < up->plan.n_tables && up->plan.tab[t + 1].first <= i) ++t;
+            chain[i] = tw_chain_entry(&tree, &up->plan, t, i - up->plan.tab[t].first);
+            continue;
+        }
         const uint32_t r = idx >> 8, f = idx & 255u;
         uint32_t node = r < n_int ? r : 0, n = 0, first = 0;
         const uint32_t skip = r < n_int ? 0 : r - n_int + 1;
@@ -352,9 +363,10 @@ __global__ __launch_bounds__(256) void k_tw_check(const uint32_t *__restrict__ b
 }
 
 // ---- launch wrappers --------------------------------------------------------------------------------
-void launch_tw_build(hipStream_t stream, const TwTree *d_tree, uint32_t n_int, uint16_t *table) {
-    const uint32_t entries = tw_table_entries(n_int);
-    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_tree, n_int, table);
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain) {
+    const uint32_t entries = (table ? tw_table_entries(n_int) : 0) + (chain ? n_chain : 0);
+    if (!entries) return;
+    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_up, n_int, table, chain ? n_chain : 0u, chain);
 }
 
 void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, const uint16_t *table,

@@ -163,6 +163,16 @@ int et_selftest_decode_tables(et_ctx *ctx, const et_codebook *cb, int *where);
  * *first_diff = 1 + the first differing entry. */
 int et_treewalk_table(const et_codebook *cb, uint16_t *table, size_t cap_entries, uint32_t *n_int);
 int et_selftest_treewalk_table(et_ctx *ctx, const et_codebook *cb, uint32_t *first_diff);
+/* Under the same condition the write pass (decode.zig:143-203 again, now emitting symbols) looks codewords up in
+ * CHAINED tables: a root table indexed by the next 11 bits, and for every tree node such an index can end on
+ * without completing a codeword a table of its own; each entry names the table of the NEXT lookup, so a long code
+ * is one more step of its lane, not an exception (csrc/et_treewalk.h).  et_chain_tables: the tables as the host
+ * fills them (u64 entries: lo = i16 (symbols << 10) - bits | first symbol << 16 | bits to the end of the first
+ * symbol << 24; hi = byte offset of the next table | second symbol << 16 | (32 - its index bits) << 24), and where
+ * each table begins / how many index bits it has.  et_selftest_treewalk_table compares the device fill of these
+ * as well (*first_diff counts on behind the tree-walk table's entries). */
+int et_chain_tables(const et_codebook *cb, uint64_t *table, size_t cap_entries, uint32_t *n_entries, uint32_t *table_first, uint8_t *table_bits,
+                    size_t cap_tables, uint32_t *n_tables);
 
 /* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */
 int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols);

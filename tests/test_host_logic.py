@@ -302,3 +302,90 @@ def test_treewalk_table_against_brute_force():
     d[65], l[65], d[66], l[66] = 0b0, 1, 0b10, 2  # "11" is missing
     gap = Codebook.from_tables(d, l)
     assert N.lib().et_treewalk_table(ctypes.byref(gap.raw), None, 0, ctypes.byref(n_int)) == N.ET_ERR_UNSUPPORTED
+
+
+def _chain_tables(cb):
+    import ctypes
+
+    from entreepy_amd import _native as N
+
+    n_entries, n_tables = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    table = np.zeros(4096, dtype=np.uint64)
+    first = np.zeros(256, dtype=np.uint32)
+    bits = np.zeros(256, dtype=np.uint8)
+    rc = N.lib().et_chain_tables(ctypes.byref(cb.raw), table.ctypes.data, table.size, ctypes.byref(n_entries), first.ctypes.data, bits.ctypes.data, 256,
+                                 ctypes.byref(n_tables))
+    assert rc == N.ET_OK
+    return table[: n_entries.value], first[: n_tables.value], bits[: n_tables.value]
+
+
+def _decode_through_chain(table, stream_bits, n_symbols):
+    """Greedy multi-symbol decode of a bit list through the chained tables, following every entry's own "next table"
+    and "next shift" fields the way the write walk does (window = the next 32 bits, zero-padded)."""
+    out = []
+    pos, t_off, shift = 0, 0, 32 - 11
+    padded = stream_bits + [0] * 64
+    while len(out) < n_symbols:
+        window = 0
+        for b in padded[pos : pos + 32]:
+            window = (window << 1) | b
+        e = int(table[t_off // 8 + (window >> shift)])
+        lo, hi = e & 0xFFFFFFFF, e >> 32
+        adv = lo & 0xFFFF
+        if adv & 0x8000:
+            adv -= 0x10000
+        n = (adv + 15) >> 10
+        used = (n << 10) - adv
+        assert 1 <= used <= 11 and 0 <= n <= 2
+        if n >= 1:
+            out.append((lo >> 16) & 0xFF)
+            assert 1 <= (lo >> 24) <= used
+        else:
+            assert (lo >> 24) == 0
+        if n == 2:
+            out.append((hi >> 16) & 0xFF)
+        pos += used
+        t_off, shift = hi & 0xFFFF, hi >> 24
+        if n >= 1:
+            assert t_off == 0 and shift == 32 - 11
+    return out[:n_symbols], pos
+
+
+def test_chain_tables_decode_what_the_codes_say():
+    """The chained lookup tables of the write walk (et_chain_tables: tw_chain_plan + tw_chain_entry, the same code the
+    device fill runs): decoding random symbol strings through them gives the strings back, for short, deep (Fibonacci
+    weights: codes up to 32 bits), flat, two-symbol and enwik-like code tables; the plan respects its bounds."""
+    from entreepy_amd.codec import Codebook
+
+    from . import corpus
+
+    rng = np.random.default_rng(11)
+    hists = []
+    for k in (2, 3, 17, 93, 256):
+        h = np.zeros(256, dtype=np.uint64)
+        h[rng.choice(256, size=k, replace=False)] = rng.integers(1, 1 << 20, size=k)
+        hists.append(h)
+    fib = np.zeros(256, dtype=np.uint64)
+    a, b = 1, 1
+    for s in range(33):  # 33 Fibonacci weights: a 32-level caterpillar
+        fib[s + 40] = a
+        a, b = b, a + b
+    hists.append(fib)
+    hists.append(np.ones(256, dtype=np.uint64))  # flat 8-bit codes
+    hists.append((corpus.enwik_like_distribution() * (1 << 40)).astype(np.uint64))
+    hists.append((corpus.midsummer_distribution() * (1 << 30)).astype(np.uint64))
+    for h in hists:
+        cb = Codebook.from_histogram(h)
+        assert cb.raw.max_length <= 32
+        table, first, bits = _chain_tables(cb)
+        assert first[0] == 0 and bits[0] == 11 and table.size == int((1 << bits.astype(np.uint32)).sum())
+        assert table.size <= 2048 + 576 and first.size <= 256
+        coded = np.flatnonzero(cb.length)
+        # every symbol appears, the long ones often: uniform over the coded symbols
+        text = rng.choice(coded, size=3000)
+        stream = []
+        for s in text:
+            L = int(cb.length[s])
+            stream += [(int(cb.data[s]) >> i) & 1 for i in range(L - 1, -1, -1)]
+        got, pos = _decode_through_chain(table, stream, text.size)
+        assert got == [int(s) for s in text]
