@@ -175,6 +175,8 @@ def main():
         phases["dec_body"] += t["body_ms"]
         phases["dec_total"] += t["total_ms"]
         phases["sync_launches"] += t["sync_iters"]
+        state["sync_kernel"] = "k_tw_sync" if t["tree_walk_sync"] else "k_dec_sync_reg2"
+        state["write_kernel"] = "k_dec_write_chain" if t["chained_write"] else "k_dec_write_reg"
 
     # The HIP events of every call are recorded inside the timed region; their elapsed
     # times are READ where reading cannot stall the stream: the decode's after the next
@@ -280,8 +282,8 @@ def main():
             # that dispatch, no marker packets), recorded in every step of the timed region.
             "k_hist_tiles": (ms["hist"], n),
             "k_encode_tiles": (ms["enc_body"], n + m_bytes),
-            "k_tw_sync": (ms["dec_sync_first"], m_bytes),
-            "k_dec_write_reg": (ms["dec_body"], m_bytes + n),
+            state["sync_kernel"]: (ms["dec_sync_first"], m_bytes),
+            state["write_kernel"]: (ms["dec_body"], m_bytes + n),
         }
         dominant = max(kernels, key=lambda k: kernels[k][0])
         d_ms, d_bytes = kernels[dominant]

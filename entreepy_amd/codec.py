@@ -189,6 +189,7 @@ class Context:
         d = {k: getattr(t, k) for k, _ in N.Timings._fields_ if k not in ("reserved", "pad_")}
         d["exhaustive_sync"] = bool(t.reserved & 1)
         d["tree_walk_sync"] = bool(t.reserved & 2)
+        d["chained_write"] = bool(t.reserved & 4)
         return d
 
     def last_codebook(self):

@@ -61,6 +61,7 @@ struct et_ctx {
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
     DevBuf tw_table, tw_tree, blk_start, chain_table;      // tree-walk synchronisation, chained write tables (et_treewalk.h)
     et::TwUpload *h_tw_tree[2] = {};                       // pinned, used in turn like h_lut_buf
+    int tw_turn = 0;
     // staging for the host-pointer / file-descriptor entry points
     DevBuf io_in, io_out;
     et_io::Pipe *io = nullptr;  // pinned double buffer + copy threads, made on first use
@@ -931,10 +932,27 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
 
     ctx->range.valid = false;  // shares the workspaces
     const double t0 = now_ms();
-    et::DecodeTables tb, tb_write;
+    // Which tables this decode needs.  A full code tree (an encoder's always is) and a stream of more than a few
+    // blocks: the tree walk's table and the chained write tables (et_treewalk.h), both filled by ONE small launch
+    // from the tree -- the lookup tables of the LDS-window / register-window kernels are then built only if the
+    // stream turns out to need them (it does not synchronise: exhaustive path).  Otherwise those, up front.
+    et::DecodeTables tb{}, tb_write{};
     ET_TRY(ensure(ctx, ctx->flag, 64));
-    bool flags_zeroed = false;
-    ET_TRY(prepare_decode_tables(ctx, cb, &tb, &tb_write, static_cast<uint32_t *>(ctx->flag.p), &flags_zeroed));
+    bool flags_zeroed = false, have_tables = false;
+    auto need_tables = [&](bool zero_flags) -> int {
+        if (have_tables) return ET_OK;
+        have_tables = true;
+        return prepare_decode_tables(ctx, cb, &tb, &tb_write, zero_flags ? static_cast<uint32_t *>(ctx->flag.p) : nullptr, zero_flags ? &flags_zeroed : nullptr);
+    };
+    // A (nearly) fixed-length code has nothing to re-synchronise on: do not even try.
+    bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
+    et::TwUpload *h_up = nullptr;
+    if (n_blocks > 3) {
+        h_up = ctx->h_tw_tree[ctx->tw_turn ^= 1];  // two pinned blocks in turn, as prepare_decode_tables' (this call waits for its flags before it returns)
+        if (et::tw_build_tree(cb, &h_up->tree) != ET_OK) h_up = nullptr;
+    }
+    const bool tw_sweeps = h_up && !exhaustive && n_blocks >= 16;
+    if (!tw_sweeps) ET_TRY(need_tables(true));
     const double t1 = now_ms();
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
@@ -980,33 +998,27 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ET_HIP(hipGetLastError());
         return ET_OK;
     };
-    // A (nearly) fixed-length code has nothing to re-synchronise on: do not even try.
-    bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
     bool more_sweeps = false;
-    // The synchronisation sweeps by tree walk (et_treewalk.h) when the code table is a full tree -- an
-    // encoder's always is -- and the stream is more than a few blocks; the register-window sweeps otherwise.
-    // The write walk over chained lookup tables (no escapes) under the same condition, whatever the sweeps are.
-    if (n_blocks > 3) {
-        et::TwUpload *h_up = ctx->h_tw_tree[ctx->lut_turn];  // (prepare_decode_tables has just flipped the turn: this one is free)
-        if (et::tw_build_tree(cb, &h_up->tree) == ET_OK) {
-            et::tw_chain_plan(&h_up->tree, &h_up->plan);
-            const bool sweeps = !exhaustive && n_blocks >= 16;
-            ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwUpload)));
-            ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
-            if (sweeps) {
-                ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
-                ET_TRY(ensure(ctx, ctx->blk_start, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
-            }
-            tw_n_int = h_up->tree.n_int;
-            n_chain = h_up->plan.n_entries;
-            ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, h_up, et::tw_upload_bytes(h_up), hipMemcpyHostToDevice, ctx->stream));
-            et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), tw_n_int, sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr,
-                                n_chain, static_cast<uint64_t *>(ctx->chain_table.p));
-            chain = static_cast<const uint64_t *>(ctx->chain_table.p);
-            if (sweeps) {
-                tw_table = static_cast<const uint16_t *>(ctx->tw_table.p);
-                blk_start = static_cast<uint32_t *>(ctx->blk_start.p);
-            }
+    // The synchronisation sweeps by tree walk and the write walk over chained lookup tables (no escapes).
+    if (h_up) {
+        et::tw_chain_plan(&h_up->tree, &h_up->plan);
+        ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwUpload)));
+        ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
+        if (tw_sweeps) {
+            ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
+            ET_TRY(ensure(ctx, ctx->blk_start, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+        }
+        tw_n_int = h_up->tree.n_int;
+        n_chain = h_up->plan.n_entries;
+        ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, h_up, et::tw_upload_bytes(h_up), hipMemcpyHostToDevice, ctx->stream));
+        const bool zero_here = !flags_zeroed && !exhaustive;
+        et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), tw_n_int, tw_sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr, n_chain,
+                            static_cast<uint64_t *>(ctx->chain_table.p), zero_here ? flag : nullptr);
+        flags_zeroed = flags_zeroed || zero_here;
+        chain = static_cast<const uint64_t *>(ctx->chain_table.p);
+        if (tw_sweeps) {
+            tw_table = static_cast<const uint16_t *>(ctx->tw_table.p);
+            blk_start = static_cast<uint32_t *>(ctx->blk_start.p);
         }
     }
     auto scan_and_total_tw = [&]() -> int {
@@ -1045,6 +1057,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (!et::dec_state_final(h_flags[1], h_flags[2], n_blocks)) wrote = false;  // the speculative launch declined by the same rule
     }
     if (exhaustive) {
+        ET_TRY(need_tables(false));
         if (iters == 0) {  // no first sweep carried the events: plain markers in front of the exhaustive kernels
             record(ctx, EV_DEC + 0);
             record(ctx, EV_DEC + 5);

@@ -133,8 +133,9 @@ void tw_chain_fill(const TwTree *tree, const ChainPlan *plan, uint64_t *table);
 namespace et {
 
 // table: tw_table_entries(n_int) u16 in device memory (or null), chain: n_chain u64 (or null); both filled from a
-// TwUpload in device memory (tw_upload_bytes of it) by one launch.
-void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain);
+// TwUpload in device memory (tw_upload_bytes of it) by one launch.  zero16 (optional): 16 words the kernel also clears
+// (the decode's flags).
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16 = nullptr);
 
 // D1 by tree walk.  Outputs as the register-window sweep's: sub_state[s] = start bit | (start bit of s + 1) << 8
 // | codewords that begin in s << 16; blk_count[b]; and, as ROWS instead of bit offsets, blk_exit[b] = the tree

@@ -51,8 +51,9 @@ __device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__
 // One launch fills both tables of a code: the synchronisation walk's (table, may be null) and the write walk's chained
 // lookup tables (chain, may be null; tw_chain_entry is the definition, shared with the host fill).
 __global__ __launch_bounds__(1024) void k_tw_build(const TwUpload *__restrict__ up, uint32_t n_int, uint16_t *__restrict__ table, uint32_t n_chain,
-                                                   uint64_t *__restrict__ chain) {
+                                                   uint64_t *__restrict__ chain, uint32_t *__restrict__ zero16) {
     __shared__ TwTree tree;
+    if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0;  // the decode's flag words
     for (uint32_t i = threadIdx.x; i < 2 * n_int; i += 1024) tree.child[i] = up->tree.child[i];
     __syncthreads();
     const uint32_t entries = table ? tw_table_entries(n_int) : 0;
@@ -363,10 +364,10 @@ __global__ __launch_bounds__(256) void k_tw_check(const uint32_t *__restrict__ b
 }
 
 // ---- launch wrappers --------------------------------------------------------------------------------
-void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain) {
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16) {
     const uint32_t entries = (table ? tw_table_entries(n_int) : 0) + (chain ? n_chain : 0);
     if (!entries) return;
-    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_up, n_int, table, chain ? n_chain : 0u, chain);
+    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_up, n_int, table, chain ? n_chain : 0u, chain, zero16);
 }
 
 void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, const uint16_t *table,
