@@ -127,6 +127,12 @@ __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS],
         }
         // (nothing moves across a step: the compiler otherwise computes every byte offset of the walk up front and spills)
         __builtin_amdgcn_sched_barrier(0);
+        if (TRACK && j + 1 < N_STEPS) {  // looking for first completions only: done once every lane of the wavefront has seen one
+            bool open = false;
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) open = open || !t.found[u];
+            if (!__any(open)) break;
+        }
     }
 }
 
