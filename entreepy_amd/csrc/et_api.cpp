@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,8 @@ struct et_ctx {
     size_t hist_n = 0;
     uint32_t hist_rpt = 0, hist_tiles = 0;
     bool hist_on_host = false;  // h_hist holds the counts of hist_text
+    uint64_t header_epoch = 0;  // h_scalar[14] == header_epoch: the header bytes of the current decode are in h_header
+    uint64_t hist_epoch = 0;    // h_hist[256 + w] == hist_epoch: reducing workgroup w of the current histogram has stored its totals
 
     hipEvent_t ev[12] = {};  // 0..5: encode calls, EV_DEC + 0..5: decode calls
     hipEvent_t ev_flags = nullptr;  // body decode: the sweep flags and the symbol total have reached the host
@@ -223,7 +226,8 @@ double now_ms() {
 int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) {
     ET_TRY(ensure_encode_ws(ctx, g.n_tiles));
     et::launch_hist(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<uint32_t *>(ctx->tile_hist.p),
-                    static_cast<unsigned long long *>(ctx->block_hist.p), static_cast<unsigned long long *>(ctx->hist.p), timed(ctx, 0, 1));
+                    static_cast<unsigned long long *>(ctx->block_hist.p), static_cast<unsigned long long *>(ctx->hist.p),
+                    reinterpret_cast<unsigned long long *>(ctx->h_hist), ++ctx->hist_epoch, timed(ctx, 0, 1));  // (the totals land in h_hist too: fetch_histogram only waits)
     ET_HIP(hipGetLastError());
     ctx->hist_text = d_text;
     ctx->hist_n = n;
@@ -269,8 +273,23 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
 
 int fetch_histogram(et_ctx *ctx) {
     if (ctx->hist_on_host) return ET_OK;
-    ET_HIP(hipMemcpyAsync(ctx->h_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    ET_HIP(hipStreamSynchronize(ctx->stream));
+    // k_hist_reduce stores the totals into h_hist and, behind them, its workgroups' "done" words: poll those (a
+    // stream wait returns ~10 us after the kernel; this sits between the two halves of every encode).  A kernel that
+    // never gets there (a fault) is left to the stream wait to report.
+    volatile const uint64_t *done = ctx->h_hist + 256;
+    const double t0 = now_ms();
+    for (uint32_t spin = 0;; ++spin) {
+        bool all = true;
+        for (uint32_t w = 0; w < et::HIST_REDUCE_GROUPS; ++w) all = all && done[w] == ctx->hist_epoch;
+        if (all) break;
+        if ((spin & 1023u) == 1023u && now_ms() - t0 > 100.0) {
+            ET_HIP(hipStreamSynchronize(ctx->stream));
+            for (uint32_t w = 0; w < et::HIST_REDUCE_GROUPS; ++w)
+                if (done[w] != ctx->hist_epoch) return fail(ctx, ET_ERR_HIP, "the histogram never reached the host");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     ctx->hist_on_host = true;
     return ET_OK;
 }
@@ -315,7 +334,8 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     ok = ok && hipStreamCreateWithFlags(&ctx->side.stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hist), 256 * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_hist), (256 + et::HIST_REDUCE_GROUPS) * sizeof(uint64_t)) == hipSuccess;
+    if (ok) std::memset(ctx->h_hist, 0, (256 + et::HIST_REDUCE_GROUPS) * sizeof(uint64_t));  // (no workgroup's word reads as the first epoch)
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_enc), 768 * sizeof(uint32_t) + HEADER_STAGE) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_header), HEADER_STAGE) == hipSuccess;
     for (int i = 0; i < 2; ++i) {
@@ -323,6 +343,7 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     }
     ctx->h_lut = ctx->h_lut_buf[0];
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalar), 16 * sizeof(uint64_t)) == hipSuccess;
+    if (ok) std::memset(ctx->h_scalar, 0, 16 * sizeof(uint64_t));
     for (int i = 0; i < 2; ++i) ok = ok && hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tw_tree[i]), sizeof(et::TwUpload)) == hipSuccess;
     // timing-only events: no system-scope fence when they complete (hip_runtime_api.h: "for events that
     // are only being used to measure timing"); with the default flags the ten records of an
@@ -1305,9 +1326,22 @@ extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t le
     const size_t head = len < HEADER_STAGE ? len : HEADER_STAGE;
     // (no wait before the copy: an earlier encode's upload FROM the pinned header stage is
     // ahead of this copy INTO it on the same stream)
+    // A one-workgroup kernel stores the bytes into the pinned stage and then a "done" word, which the host polls (a
+    // copy command and a stream wait cost ~10 us more, between the two halves of an encode + decode pipeline).
     uint8_t *hdr_data = ctx->h_header;
-    ET_HIP(hipMemcpyAsync(hdr_data, d_compressed, head, hipMemcpyDeviceToHost, ctx->stream));
-    ET_HIP(hipStreamSynchronize(ctx->stream));
+    volatile uint64_t *done = ctx->h_scalar + 14;
+    const uint64_t epoch = ++ctx->header_epoch;
+    et::launch_bytes_to_host(ctx->stream, d_compressed, static_cast<uint32_t>(head), hdr_data, const_cast<unsigned long long *>(reinterpret_cast<volatile unsigned long long *>(done)), epoch);
+    ET_HIP(hipGetLastError());
+    {
+        const double t0 = now_ms();
+        for (uint32_t spin = 0; *done != epoch; ++spin)
+            if ((spin & 1023u) == 1023u && now_ms() - t0 > 100.0) {
+                ET_HIP(hipStreamSynchronize(ctx->stream));
+                if (*done != epoch) return fail(ctx, ET_ERR_HIP, "the header never reached the host");
+            }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     et_codebook cb;
     uint64_t n_symbols = 0;
     size_t body_offset = 0;

@@ -11,6 +11,7 @@ namespace et {
 constexpr int BLOCK = 256;                    // threads per workgroup: 4 wavefronts of 64
 constexpr uint32_t ROUND_BYTES = BLOCK * 16;  // one 16-byte load per lane
 constexpr uint32_t MAX_ROUNDS_PER_TILE = 16;  // tile <= 64 KiB (u32 tile counters, u32 bit cursors)
+constexpr uint32_t HIST_REDUCE_GROUPS = 128;   // k_hist_reduce: two histogram columns each
 constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-stride beyond
 
 constexpr uint32_t SUB_BITS = 256;                             // decode: bits per lane subsequence
@@ -70,7 +71,10 @@ struct KernelEvents {
 };
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
-                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, KernelEvents ev = {});
+                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, unsigned long long *host_hist = nullptr, unsigned long long epoch = 0,  // host_hist: 256 + HIST_REDUCE_GROUPS words of pinned host memory: the totals, and per reducing workgroup `epoch` once its two are stored
+                 KernelEvents ev = {});
+// d_src[0..n) -> host_dst (pinned host memory, 4-byte aligned, room for n rounded up to 4), then *host_done = epoch (pinned as well)
+void launch_bytes_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch);
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
                       unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
                       unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src = nullptr, uint32_t header_words = 0);  // header_src (device): the file header, copied to out32[0 .. header_words) behind the seam word's zeroing

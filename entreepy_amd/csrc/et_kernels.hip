@@ -204,13 +204,58 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__rest
     if (tid < 256) block_hist[static_cast<uint64_t>(blockIdx.x) * 256 + tid] = acc;
 }
 
-// Column sums of block_hist[n_rows][256] into hist[256] (zeroed beforehand).
+// Column sums of block_hist[n_rows][256] into hist[256]: workgroup w OWNS columns 2w and 2w + 1 (one 16-byte load
+// per row and thread), so the totals are plain stores -- no zeroing beforehand, no atomics -- and can go to two places:
+// the device's copy and, for the host's code construction that waits behind this kernel, pinned host memory (no copy
+// command in between).  128 workgroups; the strided rows cost 8 x the 2 MiB in cache lines, which is nothing.
 __global__ __launch_bounds__(BLOCK) void k_hist_reduce(const unsigned long long *__restrict__ block_hist, uint32_t n_rows,
-                                                       unsigned long long *__restrict__ hist) {
-    unsigned long long s = 0;
-#pragma unroll 8
-    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) s += block_hist[static_cast<uint64_t>(r) * 256 + threadIdx.x];
-    if (s) atomicAdd(hist + threadIdx.x, s);
+                                                       unsigned long long *__restrict__ hist, unsigned long long *__restrict__ host_hist,
+                                                       unsigned long long epoch) {
+    __shared__ unsigned long long part[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long s0 = 0, s1 = 0;
+    for (uint32_t r = tid; r < n_rows; r += BLOCK) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(block_hist + static_cast<uint64_t>(r) * 256 + 2 * blockIdx.x);
+        s0 += v.x;
+        s1 += v.y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64);
+        s1 += __shfl_xor(s1, d, 64);
+    }
+    if (lane == 0) {
+        part[0][wave] = s0;
+        part[1][wave] = s1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t0 = part[0][0] + part[0][1] + part[0][2] + part[0][3], t1 = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        hist[2 * blockIdx.x] = t0;
+        hist[2 * blockIdx.x + 1] = t1;
+        if (host_hist) {
+            // host_hist[256 ..]: one "these two are there" word per workgroup -- the host polls them instead of waiting
+            // for the stream (no completion signal, no wake-up in between)
+            host_hist[2 * blockIdx.x] = t0;
+            host_hist[2 * blockIdx.x + 1] = t1;
+            __threadfence_system();
+            __hip_atomic_store(host_hist + 256 + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// The first n bytes at src (any alignment) into pinned host memory, then `epoch` into *host_done: what the host of a
+// decode reads the header and dictionary from.  It polls the word instead of waiting for a copy command.
+__global__ __launch_bounds__(1024) void k_bytes_to_host(const uint8_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ host_dst,
+                                                        unsigned long long *__restrict__ host_done, unsigned long long epoch) {
+    for (uint32_t w = threadIdx.x; w * 4 < n; w += 1024) {
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4 && w * 4 + k < n; ++k) v |= static_cast<uint32_t>(src[w * 4 + k]) << (8 * k);
+        host_dst[w] = v;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // --------------------------------------------------------------------------------
@@ -2252,16 +2297,18 @@ static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
 }
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
-                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, KernelEvents ev) {
+                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, unsigned long long *host_hist, unsigned long long epoch, KernelEvents ev) {
     // 4 workgroups per CU are resident (LDS): 1024 = one full batch (0.227 ms at 1 GiB; 2048 = two
     // batches 0.231; 1280 or 1536 = a full and a partial batch, 0.32-0.36)
     const uint32_t grid = n_tiles < 1024u ? n_tiles : 1024u;
-    (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
     ET_LAUNCH_TIMED(k_hist_tiles, dim3(grid), dim3(HIST_BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
-    const uint32_t rgrid = grid < 128u ? grid : 128u;  // workgroups of the reduction; measured 16 / 32 / 64 / 128 / 512: 20.8 / 11.1 / 5.7 / 5.5 / 12.9 us (512: 131 K atomics on 256 addresses)
-    hipLaunchKernelGGL(k_hist_reduce, dim3(rgrid), dim3(BLOCK), 0, stream, block_hist, grid, hist);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(128), dim3(BLOCK), 0, stream, block_hist, grid, hist, host_hist, epoch);
 }
 
+
+void launch_bytes_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch) {
+    hipLaunchKernelGGL(k_bytes_to_host, dim3(1), dim3(1024), 0, stream, static_cast<const uint8_t *>(d_src), n, static_cast<uint32_t *>(host_dst), host_done, epoch);
+}
 
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
                       unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
