@@ -728,7 +728,7 @@ def test_tree_walk_sync_is_what_a_decode_runs(ctx):
         out = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
         assert ctx.decode_device(comp, out) == data.size
         t = ctx.timings("decode")
-        assert t["tree_walk_sync"] and not t["exhaustive_sync"]
+        assert t["tree_walk_sync"] and t["chained_write"] and not t["exhaustive_sync"]
         assert out[: data.size].cpu().numpy().tobytes() == data.tobytes()
     finally:
         ctx.enable_timing(False)
@@ -759,3 +759,56 @@ def test_tree_walk_sync_is_what_a_decode_runs(ctx):
         out = torch.empty(400_064, dtype=torch.uint8, device="cuda")
         m = ctx.decode_device(buf[shift : shift + len(et) - 4], out)
         assert out[:m].cpu().numpy().tobytes() == want, shift
+
+
+def test_chained_write_windows_and_long_codes(ctx):
+    """The write pass over chained lookup tables (k_dec_write_chain) where its special paths are: blocks that hold
+    more symbols than the LDS stage (1- and 2-bit codes: up to four windows per block), a long-tailed alphabet whose
+    rare symbols take two to four chained lookups, the same with the rare symbols made frequent in the STREAM (every
+    lane meets several, also as its last codeword), and streams cut inside the last block."""
+    import torch
+
+    O = _oracle()
+    rng = np.random.default_rng(77)
+    cases = []
+    cases.append(np.where(rng.random(3_000_000) < 0.9, 65, 66).astype(np.uint8))                      # 1-bit codes
+    cases.append(rng.choice(np.array([1, 2, 3, 4], dtype=np.uint8), size=2_000_000, p=[0.4, 0.3, 0.2, 0.1]))  # 1..3 bits
+    cases.append(corpus.enwik_like(4_000_000, 5))
+    # a geometric alphabet (code lengths 1 .. 24) in which the tail is as frequent as the head
+    sym = np.repeat(np.arange(25, dtype=np.uint8) + 60, np.maximum(1, (1 << 24) >> np.arange(25)))
+    rng.shuffle(sym)
+    cases.append(sym[:3_000_000])
+    ctx.enable_timing(True)
+    try:
+        for data in cases:
+            et = O.encode(data)
+            comp = torch.frombuffer(bytearray(et[4:]), dtype=torch.uint8).cuda()
+            out = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+            assert ctx.decode_device(comp, out) == data.size
+            assert ctx.timings("decode")["chained_write"]
+            assert out[: data.size].cpu().numpy().tobytes() == data.tobytes()
+            for cut in (1, 2, 3, 5, 64, 257, 8191, 8200):  # truncated bodies: whatever the oracle makes of them
+                short = et[4 : len(et) - cut]
+                assert ctx.decode(short) == O.decode(short), cut
+    finally:
+        ctx.enable_timing(False)
+    # the tail symbols FREQUENT in the stream: encode with the skewed table, decode a body assembled by hand
+    import entreepy_amd as E
+
+    hist = np.zeros(256, dtype=np.uint64)
+    hist[60:85] = np.maximum(1, (1 << 24) >> np.arange(25)).astype(np.uint64)
+    cb = E.Codebook.from_histogram(hist)
+    text = (rng.integers(0, 25, size=400_000) + 60).astype(np.uint8)  # uniform over the 25 symbols: mean length ~13 bits
+    lens = cb.length[text].astype(np.int64)
+    ends = np.cumsum(lens)
+    total = int(ends[-1])
+    bits = np.zeros(total + 64, dtype=np.uint8)
+    starts = ends - lens
+    for k in range(int(lens.max())):  # bit k of every code that has one
+        has = lens > k
+        bits[starts[has] + k] = (cb.data[text[has]] >> (lens[has] - 1 - k).astype(np.uint32)) & 1
+    body = np.packbits(bits[: (total + 7) // 8 * 8])
+    d_body = torch.from_numpy(body).cuda()
+    d_out = torch.empty(text.size + 64, dtype=torch.uint8, device="cuda")
+    assert ctx.decode_body_device(cb, d_body, text.size, d_out) == text.size
+    assert d_out[: text.size].cpu().numpy().tobytes() == text.tobytes()

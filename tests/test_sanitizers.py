@@ -330,6 +330,35 @@ TREEWALK_DRIVER = textwrap.dedent(r"""
                     return 1;
                 }
             }
+            // the write walk's chained tables: plan within its bounds, and random bits decoded through the tables
+            // (following each entry's own next-table / next-shift fields) give what the tree gives bit by bit
+            static et::ChainPlan plan;
+            static uint64_t chain[et::CH_MAX_ENTRIES];
+            et::tw_chain_plan(&tree, &plan);
+            if (plan.n_tables < 1 || plan.n_tables > et::CH_MAX_TABLES || plan.n_entries > et::CH_MAX_ENTRIES || plan.tab[0].bits != et::CH_ROOT_BITS) { std::puts("plan bounds"); return 1; }
+            et::tw_chain_fill(&tree, &plan, chain);
+            for (int w = 0; w < 60; ++w) {
+                uint8_t bits[160];
+                for (int i = 0; i < 160; ++i) bits[i] = (uint8_t)(next() & 1);
+                // bit-serial reference: symbols and the positions where they end, for the first 96 bits
+                std::vector<int> want_sym, want_end;
+                { uint32_t node = 0; for (int i = 0; i < 128; ++i) { int16_t c = tree.child[2 * node + bits[i]]; if (c >= 0) node = c; else { want_sym.push_back(et::TW_LEAF0 - c); want_end.push_back(i + 1); node = 0; } } }
+                uint32_t pos = 0, t_off = 0, shift = 32 - et::CH_ROOT_BITS; size_t got = 0;
+                while (pos < 90) {
+                    uint32_t window = 0;
+                    for (int i = 0; i < 32; ++i) window = (window << 1) | bits[pos + i];
+                    const uint64_t e = chain[t_off / 8 + (window >> shift)];
+                    const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+                    const int adv = (int16_t)(lo & 0xffffu);
+                    const int n = (adv + 15) >> 10, used = (n << 10) - adv;
+                    if (used < 1 || used > (int)et::CH_ROOT_BITS || n < 0 || n > 2) { std::puts("chain entry fields"); return 1; }
+                    if (n >= 1) { if (got >= want_sym.size() || want_sym[got] != (int)((lo >> 16) & 0xff) || want_end[got] != (int)(pos + (lo >> 24))) { std::puts("chain first symbol"); return 1; } ++got; }
+                    if (n == 2) { if (got >= want_sym.size() || want_sym[got] != (int)((hi >> 16) & 0xff) || want_end[got] != (int)(pos + used)) { std::puts("chain second symbol"); return 1; } ++got; }
+                    pos += used;
+                    t_off = hi & 0xffffu; shift = hi >> 24;
+                    if (t_off / 8 >= plan.n_entries || shift < 32 - et::CH_ROOT_BITS || shift > 31) { std::puts("chain next table"); return 1; }
+                }
+            }
         }
         // dictionaries that are not full trees (or not prefix-free) are turned away, never walked
         et_codebook bad;
