@@ -60,7 +60,7 @@ struct et_ctx {
     // decode workspaces
     DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag, worklist;  // flag: [0..3] sweep flags, [4] ticket, [8..] worklist counts  // lut: all decode tables, DEC_TABLES_BYTES
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
-    DevBuf tw_table, tw_tree, blk_start, chain_table;      // tree-walk synchronisation, chained write tables (et_treewalk.h)
+    DevBuf tw_table, tw_tree, blk_start, blk_pub, chain_table;  // tree-walk synchronisation, chained write tables (et_treewalk.h)
     et::TwUpload *h_tw_tree[2] = {};                       // pinned, used in turn like h_lut_buf
     int tw_turn = 0;
     // staging for the host-pointer / file-descriptor entry points
@@ -365,7 +365,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->group_sum,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->flag,
                       &ctx->worklist, &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
-                      &ctx->tw_table, &ctx->tw_tree, &ctx->blk_start, &ctx->chain_table, &ctx->io_in, &ctx->io_out};
+                      &ctx->tw_table, &ctx->tw_tree, &ctx->blk_start, &ctx->blk_pub, &ctx->chain_table, &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     delete ctx->io;
@@ -1028,13 +1028,14 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (tw_sweeps) {
             ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
             ET_TRY(ensure(ctx, ctx->blk_start, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_pub, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
         }
         tw_n_int = h_up->tree.n_int;
         n_chain = h_up->plan.n_entries;
         ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, h_up, et::tw_upload_bytes(h_up), hipMemcpyHostToDevice, ctx->stream));
         const bool zero_here = !flags_zeroed && !exhaustive;
         et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), tw_n_int, tw_sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr, n_chain,
-                            static_cast<uint64_t *>(ctx->chain_table.p), zero_here ? flag : nullptr);
+                            static_cast<uint64_t *>(ctx->chain_table.p), zero_here ? flag : nullptr, tw_sweeps ? static_cast<uint32_t *>(ctx->blk_pub.p) : nullptr, n_blocks);
         flags_zeroed = flags_zeroed || zero_here;
         chain = static_cast<const uint64_t *>(ctx->chain_table.p);
         if (tw_sweeps) {
@@ -1053,11 +1054,10 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (!flags_zeroed) ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
         write_ticket_zero = true;
         if (tw_table) {
+            // ONE sweep: the blocks run in, settle inside and then with the block before them (k_tw_sync's blk_pub); what
+            // that leaves open -- a block that did not re-synchronise within its 8 KiB -- the verification finds
             et::launch_tw_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tw_table, tw_n_int, sub_state, blk_exit, blk_start, blk_count, flag,
-                               et::DEC_FIRST_SWEEP_TRIPS, nullptr, nullptr, timed(ctx, EV_DEC + 0, EV_DEC + 5));
-            et::launch_tw_check(ctx->stream, blk_start, blk_exit, n_blocks, worklist, flag + 8);
-            et::launch_tw_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tw_table, tw_n_int, sub_state, blk_exit, blk_start, blk_count, flag,
-                               et::DEC_REPAIR_SWEEP_TRIPS, worklist, flag + 8);
+                               et::DEC_FIRST_SWEEP_TRIPS, nullptr, nullptr, timed(ctx, EV_DEC + 0, EV_DEC + 5), static_cast<uint32_t *>(ctx->blk_pub.p));
         } else {
             et::launch_dec_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tb, 0, et::DEC_FIRST_SWEEP_TRIPS, sub_state, blk_exit, blk_count, flag, flag + 4,
                                 et::DEC_HAVE_START, nullptr, nullptr, side, true, timed(ctx, EV_DEC + 0, EV_DEC + 5));
@@ -1065,7 +1065,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
                                 et::DEC_HAVE_START, worklist, flag + 8, side);
         }
         ET_HIP(hipGetLastError());
-        iters = 3;  // run-in sweep, repair sweep, verification
+        iters = tw_table ? 2 : 3;  // run-in sweep, (repair sweep,) verification
         if (tw_table) ET_TRY(scan_and_total_tw());
         else ET_TRY(scan_and_total(true));
         if (can_speculate) {

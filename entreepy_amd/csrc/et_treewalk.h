@@ -134,8 +134,9 @@ namespace et {
 
 // table: tw_table_entries(n_int) u16 in device memory (or null), chain: n_chain u64 (or null); both filled from a
 // TwUpload in device memory (tw_upload_bytes of it) by one launch.  zero16 (optional): 16 words the kernel also clears
-// (the decode's flags).
-void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16 = nullptr);
+// (the decode's flags); zero_words / n_zero (optional): more of them (launch_tw_sync's blk_pub).
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16 = nullptr,
+                     uint32_t *zero_words = nullptr, uint32_t n_zero = 0);
 
 // D1 by tree walk.  Outputs as the register-window sweep's: sub_state[s] = start bit | (start bit of s + 1) << 8
 // | codewords that begin in s << 16; blk_count[b]; and, as ROWS instead of bit offsets, blk_exit[b] = the tree
@@ -145,7 +146,8 @@ void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, u
 // raised when there was anything to repair).
 void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, const uint16_t *table,
                     uint32_t n_int, uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_start, uint32_t *blk_count, uint32_t *changed,
-                    uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev = {});
+                    uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev = {},
+                    uint32_t *blk_pub = nullptr);  // blk_pub (first sweep; n_blocks words, zeroed): the blocks also settle their seams with the blocks before them (see k_tw_sync)
 // Blocks whose first lane did not start where the block before ends -> worklist (n_work zeroed by the caller).
 void launch_tw_check(hipStream_t stream, const uint32_t *blk_start, const uint32_t *blk_exit, uint32_t n_blocks, uint32_t *worklist, uint32_t *n_work);
 

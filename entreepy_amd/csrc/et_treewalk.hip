@@ -51,9 +51,10 @@ __device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__
 // One launch fills both tables of a code: the synchronisation walk's (table, may be null) and the write walk's chained
 // lookup tables (chain, may be null; tw_chain_entry is the definition, shared with the host fill).
 __global__ __launch_bounds__(1024) void k_tw_build(const TwUpload *__restrict__ up, uint32_t n_int, uint16_t *__restrict__ table, uint32_t n_chain,
-                                                   uint64_t *__restrict__ chain, uint32_t *__restrict__ zero16) {
+                                                   uint64_t *__restrict__ chain, uint32_t *__restrict__ zero16, uint32_t *__restrict__ zero_words, uint32_t n_zero) {
     __shared__ TwTree tree;
     if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0;  // the decode's flag words
+    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < n_zero; i += gridDim.x * 1024) zero_words[i] = 0;  // the sweep's "published" words
     for (uint32_t i = threadIdx.x; i < 2 * n_int; i += 1024) tree.child[i] = up->tree.child[i];
     __syncthreads();
     const uint32_t entries = table ? tw_table_entries(n_int) : 0;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(1024) void k_tw_build(const TwUpload *__restrict__ 
 // ---- the walk -------------------------------------------------------------------------------------
 constexpr int TW_WORDS = 21;  // W[j] = stream word 16 * lane - 4 + j: 4 run-in words, 16 own, 1 beyond (a block's tail at the stream's end)
 constexpr int TW_LANES = 2;   // 512-bit lanes walked by one thread
+constexpr uint32_t TW_PUB_POLLS = 256;  // looks at the word the block before publishes (a short sleep in between: ~100 us in all) before a block gives up on it
 
 struct TwTrack {  // where the subsequence's first codeword begins: the bit after the first completion
     bool found[TW_LANES];
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
                                                     uint32_t n_blocks, const uint16_t *__restrict__ table, uint32_t table_entries, uint32_t n_int,
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_start,
                                                     uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed, uint32_t max_trips,
-                                                    const uint32_t *__restrict__ worklist, const uint32_t *__restrict__ n_work) {
+                                                    const uint32_t *__restrict__ worklist, const uint32_t *__restrict__ n_work, uint32_t *__restrict__ blk_pub) {
     uint16_t *tab = reinterpret_cast<uint16_t *>(tw_smem);
     const uint32_t T = blockDim.x, tid = threadIdx.x, lane_id = tid & 63;
     const uint32_t n_todo = worklist ? *n_work : n_blocks;
@@ -200,8 +202,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
     const uint64_t n_lanes = (n_subs + 1) / 2;
     const uint64_t n_words_full = n_bytes / 4;
     const uint32_t waves_per_group = T >> 6;
-    for (uint32_t it = blockIdx.x * waves_per_group + (tid >> 6); it < n_todo; it += gridDim.x * waves_per_group) {
-        const uint32_t b = worklist ? worklist[it] : it;
+    // Across blocks (first sweep, blk_pub given): a block that agrees with itself PUBLISHES the node it ends in and looks
+    // at what the block before it published; if that is not the node its first lane started from (~0.4 % of the blocks
+    // of a text) the wavefront's next trip is the same block again, from that node (`forced`).  Nobody waits for
+    // anybody who waits: what is published is a first attempt's result -- one word, stored and polled with relaxed
+    // device-scope atomics (nothing else travels with it; release/acquire here would write back and invalidate the L2
+    // of every XCD per block: the sweep took 3.6 ms instead of 0.27).  Blocks stay statically assigned: handing them out
+    // by ticket, so that a wavefront with a block to do twice takes one fewer, costs 77 K atomics on one address: 0.98 ms.
+    // (A block whose end moves in its second attempt -- it did not re-synchronise within 8 KiB -- leaves a stale word
+    // behind; the verification scan sees the mismatch and the host sweeps again.)
+    uint32_t it = blockIdx.x * waves_per_group + (tid >> 6), again_b = 0, again_row = 0xffffffffu;
+    for (;;) {
+        uint32_t b, forced = 0xffffffffu;
+        if (again_row != 0xffffffffu) {
+            b = again_b;
+            forced = again_row;
+            again_row = 0xffffffffu;
+        } else if (it < n_todo) {
+            b = worklist ? worklist[it] : it;
+            it += gridDim.x * waves_per_group;
+        } else {
+            break;
+        }
+        {
         // wavefront-uniform: every word of the block, its run-in and the word after it is a whole word of the stream
         const long long bw0 = static_cast<long long>(b) * 2048 - 4;
         const bool edge = bw0 < 0 || static_cast<uint64_t>(bw0 + 2048 + 4 + 1) > n_words_full;
@@ -243,6 +266,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             R0[0] = rem ? (n_int + rem - 1) << 9 : 0u;
         } else if (first_lane && worklist) {
             R0[0] = blk_exit[b - 1] << 9;
+        } else if (first_lane && forced != 0xffffffffu) {
+            R0[0] = forced << 9;
         }
         uint32_t start[TW_LANES];  // the row each lane's walk begins in (0 also for a known bit offset: it is a codeword boundary)
         TwLane r[TW_LANES] = {};
@@ -280,6 +305,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             else tw_lanes<false, true>(W, Rn, skip, limit, need, r);
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) start[u] = need[u] ? cand[u] : start[u];
+        }
+        if (blk_pub && !worklist && b != 0 && forced == 0xffffffffu) {
+            if (lane_id == 63) __hip_atomic_store(blk_pub + b, 0x80000000u | r[1].s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t seen = 0;
+            if (lane_id == 0) {
+                for (uint32_t poll = 0; poll < TW_PUB_POLLS && !(seen & 0x80000000u); ++poll) {
+                    seen = __hip_atomic_load(blk_pub + (b - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(seen & 0x80000000u)) __builtin_amdgcn_s_sleep(8);
+                }
+                if (!gave_up && (seen & 0x7fffffffu) == start[0]) seen = 0;  // as guessed
+            }
+            seen = __builtin_amdgcn_readfirstlane(seen);
+            if (seen & 0x80000000u) {  // (never seen: the block keeps its guess, the verification decides)
+                again_b = b;
+                again_row = seen & 0x7fffffffu;
+                continue;
+            }
+        } else if (blk_pub && !worklist && b == 0 && lane_id == 63) {
+            __hip_atomic_store(blk_pub + b, 0x80000000u | r[1].s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // Where each subsequence's first codeword begins: one past the first completion seen from the node at
         // its first bit -- four more steps per half, once the nodes are settled (tracked inside the walks it
@@ -358,6 +402,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             if (gave_up) atomicAdd(changed + 1, 1u);
             if (worklist) *changed = 1;
         }
+        }
     }
 }
 
@@ -370,15 +415,17 @@ __global__ __launch_bounds__(256) void k_tw_check(const uint32_t *__restrict__ b
 }
 
 // ---- launch wrappers --------------------------------------------------------------------------------
-void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16) {
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16,
+                     uint32_t *zero_words, uint32_t n_zero) {
     const uint32_t entries = (table ? tw_table_entries(n_int) : 0) + (chain ? n_chain : 0);
     if (!entries) return;
-    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_up, n_int, table, chain ? n_chain : 0u, chain, zero16);
+    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_up, n_int, table, chain ? n_chain : 0u, chain, zero16, zero_words,
+                       zero_words ? n_zero : 0u);
 }
 
 void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, const uint16_t *table,
                     uint32_t n_int, uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_start, uint32_t *blk_count, uint32_t *changed,
-                    uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev) {
+                    uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev, uint32_t *blk_pub) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t entries = tw_table_entries(n_int);
     const size_t smem = static_cast<size_t>(entries) * 2;
@@ -397,8 +444,8 @@ void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes,
     uint32_t grid = static_cast<uint32_t>(cus) * per_cu;
     if (grid > (n_blocks + waves - 1) / waves) grid = (n_blocks + waves - 1) / waves;
     if (worklist && grid > 64) grid = 64;  // a repair sweep: a handful of blocks (workgroups beyond the list leave at once)
-    if (ev.start || ev.stop) hipExtLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, ev.start, ev.stop, 0, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work);
-    else hipLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work);
+    if (ev.start || ev.stop) hipExtLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, ev.start, ev.stop, 0, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work, blk_pub);
+    else hipLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work, blk_pub);
 }
 
 void launch_tw_check(hipStream_t stream, const uint32_t *blk_start, const uint32_t *blk_exit, uint32_t n_blocks, uint32_t *worklist, uint32_t *n_work) {
