@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -81,6 +82,9 @@ struct et_ctx {
     size_t hist_n = 0;
     uint32_t hist_rpt = 0, hist_tiles = 0;
     bool hist_on_host = false;  // h_hist holds the counts of hist_text
+    const void *scan_buf = nullptr;  // the group_sum buffer scan_epoch_n counts on
+    size_t scan_cap = 0;
+    uint32_t scan_epoch_n = 0;
     uint64_t header_epoch = 0;  // h_scalar[14] == header_epoch: the header bytes of the current decode are in h_header
     uint64_t hist_epoch = 0;    // h_hist[256 + w] == hist_epoch: reducing workgroup w of the current histogram has stored its totals
 
@@ -197,6 +201,18 @@ int ensure_encode_ws(et_ctx *ctx, uint32_t n_tiles) {
     return ET_OK;
 }
 
+// A fresh epoch for k_scan_fused's published words in ctx->group_sum (call after the buffer is ensured): 1 .. 65535
+// within one lifetime of the zeroed buffer; a new buffer, or the counter running out, zeroes it.
+uint32_t scan_epoch(et_ctx *ctx) {
+    if (ctx->group_sum.p != ctx->scan_buf || ctx->group_sum.cap != ctx->scan_cap || ctx->scan_epoch_n >= 0xffffu) {
+        (void)hipMemsetAsync(ctx->group_sum.p, 0, ctx->group_sum.cap, ctx->stream);
+        ctx->scan_buf = ctx->group_sum.p;
+        ctx->scan_cap = ctx->group_sum.cap;
+        ctx->scan_epoch_n = 0;
+    }
+    return ++ctx->scan_epoch_n;
+}
+
 void record(et_ctx *ctx, int i) {
     if (ctx->timing) (void)hipEventRecord(ctx->ev[i], ctx->stream);
 }
@@ -261,7 +277,7 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
     ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 768 * sizeof(uint32_t) + padded, hipMemcpyHostToDevice, ctx->stream));
     et::launch_tile_scan(ctx->stream, static_cast<const uint32_t *>(ctx->tile_hist.p), g.n_tiles,
                          static_cast<const uint32_t *>(ctx->enc_table.p) + 512, static_cast<unsigned long long *>(ctx->tile_bits.p),
-                         static_cast<unsigned long long *>(ctx->group_sum.p), base_bit,
+                         static_cast<unsigned long long *>(ctx->group_sum.p), scan_epoch(ctx), base_bit,
                          static_cast<unsigned long long *>(ctx->tile_off.p), out32, static_cast<const uint32_t *>(ctx->enc_table.p) + 768,
                          static_cast<uint32_t>(padded / 4));
     ET_HIP(hipGetLastError());
@@ -866,7 +882,7 @@ extern "C" int et_selftest_treewalk_table(et_ctx *ctx, const et_codebook *cb, ui
     ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwUpload)));
     ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
     ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, up, et::tw_upload_bytes(up), hipMemcpyHostToDevice, ctx->stream));
-    et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), tree->n_int, static_cast<uint16_t *>(ctx->tw_table.p), n_chain,
+    et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), static_cast<uint32_t>(et::tw_upload_bytes(up)), tree->n_int, static_cast<uint16_t *>(ctx->tw_table.p), n_chain,
                         static_cast<uint64_t *>(ctx->chain_table.p));
     ET_HIP(hipGetLastError());
     std::vector<uint16_t> dev(entries), host(entries);
@@ -1005,7 +1021,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     uint32_t tw_n_int = 0, n_chain = 0;
     auto scan_and_total = [&](bool verify) -> int {
         // (the scan's last thread stores the flags and the total straight into the pinned h_flags)
-        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
+        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, scan_epoch(ctx), blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
                             verify ? sub_state : nullptr, blk_exit, flag + 2, first_bit, flag, h_flags);
         ET_HIP(hipGetLastError());
         ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
@@ -1032,9 +1048,9 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         }
         tw_n_int = h_up->tree.n_int;
         n_chain = h_up->plan.n_entries;
-        ET_HIP(hipMemcpyAsync(ctx->tw_tree.p, h_up, et::tw_upload_bytes(h_up), hipMemcpyHostToDevice, ctx->stream));
         const bool zero_here = !flags_zeroed && !exhaustive;
-        et::launch_tw_build(ctx->stream, static_cast<const et::TwUpload *>(ctx->tw_tree.p), tw_n_int, tw_sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr, n_chain,
+        // (the kernel reads the tree and the plan from the pinned block itself: no upload in front of it)
+        et::launch_tw_build(ctx->stream, h_up, static_cast<uint32_t>(et::tw_upload_bytes(h_up)), tw_n_int, tw_sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr, n_chain,
                             static_cast<uint64_t *>(ctx->chain_table.p), zero_here ? flag : nullptr, tw_sweeps ? static_cast<uint32_t *>(ctx->blk_pub.p) : nullptr, n_blocks);
         flags_zeroed = flags_zeroed || zero_here;
         chain = static_cast<const uint64_t *>(ctx->chain_table.p);
@@ -1044,7 +1060,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         }
     }
     auto scan_and_total_tw = [&]() -> int {
-        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, blk_off, reinterpret_cast<unsigned long long *>(flag + 12), blk_start, blk_exit, flag + 2, 0u,
+        et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, scan_epoch(ctx), blk_off, reinterpret_cast<unsigned long long *>(flag + 12), blk_start, blk_exit, flag + 2, 0u,
                             flag, h_flags, true);
         ET_HIP(hipGetLastError());
         ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
@@ -1195,7 +1211,7 @@ extern "C" int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const vo
         if (h_flags[0] == 0) break;
         if (sweeps > n_blocks + 4) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
     }
-    et::launch_dec_scan(ctx->stream, blk_count, n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), blk_off);
+    et::launch_dec_scan(ctx->stream, blk_count, n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), scan_epoch(ctx), blk_off);
     ET_HIP(hipGetLastError());
     ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     ET_HIP(hipMemcpyAsync(h_flags, sub_state, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1282,7 +1298,7 @@ extern "C" int et_decode_range_resolve(et_ctx *ctx, uint32_t in_start_bit, et_ra
                            static_cast<const uint8_t *>(ctx->lane_maps.p), static_cast<const uint8_t *>(ctx->blk_maps.p),
                            static_cast<const uint8_t *>(ctx->grp_maps.p), static_cast<uint8_t *>(ctx->blk_in.p), static_cast<uint8_t *>(ctx->grp_in.p),
                            sub_state, blk_exit, blk_count);
-    et::launch_dec_scan(ctx->stream, blk_count, rs.n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), blk_off);
+    et::launch_dec_scan(ctx->stream, blk_count, rs.n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), scan_epoch(ctx), blk_off);
     ET_HIP(hipGetLastError());
     ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + rs.n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     ET_HIP(hipMemcpyAsync(h_flags, sub_state, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1331,7 +1347,7 @@ extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t le
     uint8_t *hdr_data = ctx->h_header;
     volatile uint64_t *done = ctx->h_scalar + 14;
     const uint64_t epoch = ++ctx->header_epoch;
-    et::launch_bytes_to_host(ctx->stream, d_compressed, static_cast<uint32_t>(head), hdr_data, const_cast<unsigned long long *>(reinterpret_cast<volatile unsigned long long *>(done)), epoch);
+    et::launch_header_to_host(ctx->stream, d_compressed, static_cast<uint32_t>(head), hdr_data, const_cast<unsigned long long *>(reinterpret_cast<volatile unsigned long long *>(done)), epoch);
     ET_HIP(hipGetLastError());
     {
         const double t0 = now_ms();
@@ -1345,9 +1361,10 @@ extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t le
     et_codebook cb;
     uint64_t n_symbols = 0;
     size_t body_offset = 0;
-    // Parsing only needs the dictionary; give the parser the true length when the
-    // stream is short so that truncation is detected, else the staged prefix.
-    int rc = et_parse_header(hdr_data, head, &cb, &n_symbols, &body_offset);
+    // Parsing only needs the dictionary (the kernel has sent as many bytes as one with that many entries can
+    // have); give the parser the true length when the stream is short so that truncation is detected.
+    const size_t sent = std::min<size_t>(head, et::header_bound(hdr_data[0]));
+    int rc = et_parse_header(hdr_data, sent, &cb, &n_symbols, &body_offset);
     if (rc != ET_OK) return fail(ctx, rc, "et_parse_header");
     if (body_offset > len) return fail(ctx, ET_ERR_FORMAT, "dictionary runs past the end of the stream");
     return et_decode_body_device(ctx, &cb, static_cast<const uint8_t *>(d_compressed) + body_offset, len - body_offset, 0, n_symbols, d_out, cap, out_len);

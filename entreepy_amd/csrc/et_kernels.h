@@ -73,10 +73,14 @@ struct KernelEvents {
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, unsigned long long *host_hist = nullptr, unsigned long long epoch = 0,  // host_hist: 256 + HIST_REDUCE_GROUPS words of pinned host memory: the totals, and per reducing workgroup `epoch` once its two are stored
                  KernelEvents ev = {});
-// d_src[0..n) -> host_dst (pinned host memory, 4-byte aligned, room for n rounded up to 4), then *host_done = epoch (pinned as well)
-void launch_bytes_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch);
+// Bytes that hold the header and the dictionary of a stream whose first byte is d (decode.zig:34: d + 1 entries of at
+// most 8 + 8 + 32 bits behind 5 header bytes), rounded up.
+__host__ __device__ inline uint32_t header_bound(uint8_t d) { return 8u + 6u * (static_cast<uint32_t>(d) + 1u); }
+// the first min(n, header_bound(d_src[0])) bytes of d_src -> host_dst (pinned host memory, 4-byte aligned, room for that
+// rounded up to 4), then *host_done = epoch (pinned as well)
+void launch_header_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch);
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
-                      unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
+                      unsigned long long *tile_bits, unsigned long long *group_sum, uint32_t epoch, unsigned long long base_bit,  // group_sum, epoch: k_scan_fused's pub words (zeroed once) and a value in 1 .. 65535 not used on them since
                       unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src = nullptr, uint32_t header_words = 0);  // header_src (device): the file header, copied to out32[0 .. header_words) behind the seam word's zeroing
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32, KernelEvents ev = {});
@@ -100,7 +104,7 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
 // zero16 (optional): 16 words the kernel also clears (the decode's flags).
 void launch_build_dec_tables(hipStream_t stream, const TablePlan *d_plan, uint32_t *lut, uint32_t *longc, uint16_t *sub, uint8_t *sym_len,
                              uint32_t *steps, uint32_t *wsteps, uint32_t *zero16 = nullptr);
-void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
+void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum, uint32_t epoch,
                      unsigned long long *blk_off, unsigned long long *total_copy = nullptr, const uint32_t *verify_state = nullptr,
                      const uint32_t *verify_exit = nullptr, uint32_t *verify_flag = nullptr, uint32_t verify_first = 0xffffffffu,
                      const uint32_t *report_src = nullptr, uint32_t *report_dst = nullptr,  // report_dst: 14 words of pinned host memory (flags 0..11 of report_src, symbol total)

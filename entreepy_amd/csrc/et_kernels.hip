@@ -3,7 +3,7 @@
 // LDS pipe (atomics + table reads) and VALU issue.
 //
 //   encode.zig:43-47   -> k_hist_tiles (+ k_hist_reduce)          "K1"
-//   encode.zig:308-313 -> k_tile_bits, k_scan_local/_finish       "K2" (the serial
+//   encode.zig:308-313 -> k_tile_bits, k_scan_fused               "K2" (the serial
 //                         bits_written counter turned into a scan over tiles)
 //   encode.zig:303-315 -> k_encode_tiles / k_encode_tiles_long    "K4"
 //   decode.zig:143-203 -> "D1..D3": k_dec_sync_reg2 (first sweep, 512-bit lanes in registers),
@@ -244,10 +244,14 @@ __global__ __launch_bounds__(BLOCK) void k_hist_reduce(const unsigned long long 
     }
 }
 
-// The first n bytes at src (any alignment) into pinned host memory, then `epoch` into *host_done: what the host of a
-// decode reads the header and dictionary from.  It polls the word instead of waiting for a copy command.
-__global__ __launch_bounds__(1024) void k_bytes_to_host(const uint8_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ host_dst,
-                                                        unsigned long long *__restrict__ host_done, unsigned long long epoch) {
+// The header and dictionary at src (any alignment; at most n bytes) into pinned host memory, then `epoch` into
+// *host_done: what the host of a decode parses.  It polls the word instead of waiting for a copy command.  The first
+// byte says how many dictionary entries follow the 5 header bytes (decode.zig:34), an entry is at most 8 + 8 + 32 bits:
+// ET_HEADER_BOUND bytes are enough, whatever the codes are.
+__global__ __launch_bounds__(1024) void k_header_to_host(const uint8_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ host_dst,
+                                                         unsigned long long *__restrict__ host_done, unsigned long long epoch) {
+    const uint32_t bound = header_bound(src[0]);
+    if (bound < n) n = bound;
     for (uint32_t w = threadIdx.x; w * 4 < n; w += 1024) {
         uint32_t v = 0;
         for (uint32_t k = 0; k < 4 && w * 4 + k < n; ++k) v |= static_cast<uint32_t>(src[w * 4 + k]) << (8 * k);
@@ -288,20 +292,38 @@ __global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict_
 // verify_state / verify_exit / verify_flag (decode only, else null): the scan's thread i also
 // checks that block i's first subsequence started where block i-1 ended (the "sweep that
 // changes nothing" of the synchronisation, folded in here) and raises *verify_flag if not.
+// Exclusive scan of in[0..n) into out[0..n] (+ base), ONE launch: every group of 1024 scans its own elements, publishes
+// its total and adds up the totals of the groups before it as they appear -- nobody waits for anybody who waits (a
+// group's total needs nothing from outside), groups start in index order, and the words travel as relaxed device-scope
+// atomics.  pub[g] = epoch << 48 | mismatch << 47 | total: the caller hands a fresh epoch (1 .. 65535 within one
+// lifetime of the zeroed buffer) instead of zeroing the words before every launch.
+// K2's extras: the words that hold a tile boundary are zeroed, the header is copied in.  D2's extras: every block must
+// have started where the block before it ended (verify_*), and the last group reports flags and total to the host.
+constexpr unsigned long long SCAN_TOTAL_MASK = (1ull << 47) - 1ull;
+constexpr uint32_t SCAN_POLLS = 1u << 22;  // (seconds: a group below that never publishes means a dead device; the launch still ends)
 template <typename T>
-__global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out,
-                                                     unsigned long long *__restrict__ group_sum, const uint32_t *__restrict__ verify_state,
-                                                     const uint32_t *__restrict__ verify_exit, uint32_t *__restrict__ verify_flag,
-                                                     uint32_t verify_first, uint32_t verify_stride, uint32_t verify_mask) {
-    __shared__ unsigned long long wsum[16];
+__global__ __launch_bounds__(1024) void k_scan_fused(const T *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out,
+                                                     unsigned long long *__restrict__ pub, uint32_t epoch, unsigned long long base,
+                                                     uint32_t *__restrict__ zero_words, const uint32_t *__restrict__ header_src, uint32_t header_words,
+                                                     unsigned long long *__restrict__ total_copy, const uint32_t *__restrict__ verify_state,
+                                                     const uint32_t *__restrict__ verify_exit, uint32_t *__restrict__ verify_flag, uint32_t verify_first,
+                                                     uint32_t verify_stride, uint32_t verify_mask, const uint32_t *__restrict__ report_src,
+                                                     uint32_t *__restrict__ report_dst) {
+    __shared__ unsigned long long wsum[16], psum[16];
+    __shared__ uint32_t bad_any;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t i = blockIdx.x * 1024 + tid;
+    const uint32_t g = blockIdx.x, i = g * 1024 + tid;
+    if (tid == 0) bad_any = 0;
+    __syncthreads();
     // (block 0 must have started at verify_first, the stream's known first bit; 0xffffffff: not checked)
     if (verify_state && i < n) {
         const uint32_t want = i > 0 ? verify_exit[i - 1] : verify_first;
         // (verify_state: the start each block's first lane used -- sub_state, every BLOCK-th entry's low byte, a bit
         // offset; or the tree walk's blk_start, a row -- against what the block before ended on)
-        if (want != 0xffffffffu && (verify_state[static_cast<uint64_t>(i) * verify_stride] & verify_mask) != want) *verify_flag = 1;
+        if (want != 0xffffffffu && (verify_state[static_cast<uint64_t>(i) * verify_stride] & verify_mask) != want) {
+            *verify_flag = 1;  // (for the kernels behind this one)
+            bad_any = 1;
+        }
     }
     const unsigned long long x = (i < n) ? static_cast<unsigned long long>(in[i]) : 0ull;
     const unsigned long long inc = wave_inclusive_scan64(x);
@@ -309,34 +331,43 @@ __global__ __launch_bounds__(1024) void k_scan_local(const T *__restrict__ in, u
     __syncthreads();
     unsigned long long before = 0;
     for (int w = 0; w < wave; ++w) before += wsum[w];
-    if (i < n) out[i] = before + inc - x;
-    if (tid == 1023) group_sum[blockIdx.x] = before + inc;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__restrict__ out, uint32_t n,
-                                                      const unsigned long long *__restrict__ group_sum, unsigned long long base,
-                                                      uint32_t *__restrict__ zero_words, unsigned long long *__restrict__ total_copy,
-                                                      const uint32_t *__restrict__ report_src, uint32_t *__restrict__ report_dst,
-                                                      const uint32_t *__restrict__ header_src, uint32_t header_words) {
-    __shared__ unsigned long long wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t g = blockIdx.x;
-    unsigned long long part = 0;
-    for (uint32_t j = tid; j < g; j += 1024) part += group_sum[j];
+    const unsigned long long mine = before + inc - x;
+    unsigned long long group_total = 0;
+    for (int w = 0; w < 16; ++w) group_total += wsum[w];
+    const unsigned long long tag = static_cast<unsigned long long>(epoch) << 48;
+    if (tid == 0) __hip_atomic_store(pub + g, tag | (bad_any ? 1ull << 47 : 0ull) | (group_total & SCAN_TOTAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the groups before this one
+    unsigned long long part = 0, bad = 0;
+    for (uint32_t j = tid; j < g; j += 1024) {
+        unsigned long long v = 0;
+        for (uint32_t poll = 0; poll < SCAN_POLLS; ++poll) {
+            v = __hip_atomic_load(pub + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 48) == epoch) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        part += v & SCAN_TOTAL_MASK;
+        bad |= (v >> 47) & 1ull;
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-    if (lane == 0) wsum[wave] = part;
+    for (int d = 32; d >= 1; d >>= 1) {
+        part += __shfl_xor(part, d, 64);
+        bad |= __shfl_xor(bad, d, 64);
+    }
+    if (lane == 0) psum[wave] = part | (bad << 63);
     __syncthreads();
     unsigned long long prefix = base;
-    for (int w = 0; w < 16; ++w) prefix += wsum[w];
-    const uint32_t i = g * 1024 + tid;
+    bool bad_before = false;
+    for (int w = 0; w < 16; ++w) {
+        prefix += psum[w] & ~(1ull << 63);
+        bad_before = bad_before || (psum[w] >> 63);
+    }
     // The word the first tile starts in (the header/body seam of a head shard) is zeroed by ONE
     // thread, element 0's, so that the header can be copied over it below without a race: tiles
     // that begin in the same word (zero-bit tiles: text of nothing but the symbol the reference
     // drops, quirk Q1) and the stream's end leave it alone.
     const unsigned long long seam = base >> 5;
     if (i < n) {
-        const unsigned long long v = out[i] + prefix;
+        const unsigned long long v = mine + prefix;
         out[i] = v;
         // (K4 merges with atomicOr into the word a tile ENDS in when that end is not word-aligned: the next
         // tile's first word, zeroed here by that tile's thread, or the stream's last word, below; a tile that
@@ -346,15 +377,17 @@ __global__ __launch_bounds__(1024) void k_scan_finish(unsigned long long *__rest
         if (zero_words && (i == 0 || ((v & 31) && (v >> 5) != seam))) zero_words[v >> 5] = 0;
     }
     if (g == gridDim.x - 1 && tid == 0) {
-        const unsigned long long total = prefix + group_sum[g];
+        const unsigned long long total = prefix + group_total;
         out[n] = total;
         if (total_copy) *total_copy = total;  // next to the sweep flags
         if (zero_words && (total >> 5) != seam && (total & 31)) zero_words[total >> 5] = 0;  // (no open word at a word-aligned end)
         if (report_dst) {
             // the decode's report to the host, stored straight into pinned host memory (no copy
             // command between this kernel and the write kernel behind it): words 0..11 = the
-            // sweeps' flags, final since the kernels before this one; 12..13 = the symbol total
+            // sweeps' flags, final since the kernels before this one -- but for word 2, "the verification
+            // failed", which is this kernel's own: what the groups before reported with their totals, and this one
             for (int k = 0; k < 12; ++k) report_dst[k] = report_src[k];
+            if (verify_state) report_dst[2] = (bad_before || bad_any) ? 1u : 0u;
             report_dst[12] = static_cast<uint32_t>(total);
             report_dst[13] = static_cast<uint32_t>(total >> 32);
             __threadfence_system();
@@ -2157,7 +2190,7 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
     }
 }
 
-// D2 (scan of the workgroup symbol counts) is k_scan_local / k_scan_finish above.
+// D2 (scan of the workgroup symbol counts) is k_scan_fused above.
 
 // D3: decode every subsequence from its synchronised start and write the symbols.
 // Symbols are staged in LDS so that the workgroup's contiguous output range leaves
@@ -2306,19 +2339,20 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
 }
 
 
-void launch_bytes_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch) {
-    hipLaunchKernelGGL(k_bytes_to_host, dim3(1), dim3(1024), 0, stream, static_cast<const uint8_t *>(d_src), n, static_cast<uint32_t *>(host_dst), host_done, epoch);
+void launch_header_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch) {
+    hipLaunchKernelGGL(k_header_to_host, dim3(1), dim3(1024), 0, stream, static_cast<const uint8_t *>(d_src), n, static_cast<uint32_t *>(host_dst), host_done, epoch);
 }
 
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
-                      unsigned long long *tile_bits, unsigned long long *group_sum, unsigned long long base_bit,
+                      unsigned long long *tile_bits, unsigned long long *group_sum, uint32_t epoch, unsigned long long base_bit,
                       unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src, uint32_t header_words) {
     uint32_t grid = (n_tiles + 3) / 4;
     if (grid > MAX_GRID) grid = MAX_GRID;
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
     const uint32_t groups = (n_tiles + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), 0xffffffffu, 0u, 0u);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, tile_off, n_tiles, group_sum, base_bit, out32, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), header_src, header_words);
+    hipLaunchKernelGGL(k_scan_fused<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, epoch, base_bit, out32, header_src,
+                       header_words, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr),
+                       static_cast<uint32_t *>(nullptr), 0xffffffffu, 0u, 0u, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr));
 }
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
@@ -2581,13 +2615,13 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
                        blk_count);
 }
 
-void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum,
+void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum, uint32_t epoch,
                      unsigned long long *blk_off, unsigned long long *total_copy, const uint32_t *verify_state, const uint32_t *verify_exit,
                      uint32_t *verify_flag, uint32_t verify_first, const uint32_t *report_src, uint32_t *report_dst, bool verify_rows) {
     const uint32_t groups = (n_blocks + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, verify_state, verify_exit, verify_flag, verify_first,
-                       verify_rows ? 1u : static_cast<uint32_t>(BLOCK), verify_rows ? 0xffffffffu : 0xffu);
-    hipLaunchKernelGGL(k_scan_finish, dim3(groups), dim3(1024), 0, stream, blk_off, n_blocks, group_sum, 0ull, static_cast<uint32_t *>(nullptr), total_copy, report_src, report_dst, static_cast<const uint32_t *>(nullptr), 0u);
+    hipLaunchKernelGGL(k_scan_fused<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, epoch, 0ull, static_cast<uint32_t *>(nullptr),
+                       static_cast<const uint32_t *>(nullptr), 0u, total_copy, verify_state, verify_exit, verify_flag, verify_first,
+                       verify_rows ? 1u : static_cast<uint32_t>(BLOCK), verify_rows ? 0xffffffffu : 0xffu, report_src, report_dst);
 }
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,

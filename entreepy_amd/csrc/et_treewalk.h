@@ -132,10 +132,10 @@ void tw_chain_fill(const TwTree *tree, const ChainPlan *plan, uint64_t *table);
 
 namespace et {
 
-// table: tw_table_entries(n_int) u16 in device memory (or null), chain: n_chain u64 (or null); both filled from a
-// TwUpload in device memory (tw_upload_bytes of it) by one launch.  zero16 (optional): 16 words the kernel also clears
+// table: tw_table_entries(n_int) u16 in device memory (or null), chain: n_chain u64 (or null); both filled by one
+// launch from a TwUpload (up_bytes = tw_upload_bytes of it) in device memory or in pinned host memory.  zero16 (optional): 16 words the kernel also clears
 // (the decode's flags); zero_words / n_zero (optional): more of them (launch_tw_sync's blk_pub).
-void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16 = nullptr,
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t up_bytes, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16 = nullptr,
                      uint32_t *zero_words = nullptr, uint32_t n_zero = 0);
 
 // D1 by tree walk.  Outputs as the register-window sweep's: sub_state[s] = start bit | (start bit of s + 1) << 8

@@ -50,21 +50,23 @@ __device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__
 // ---- the table, filled on the device from the tree -------------------------------------------------
 // One launch fills both tables of a code: the synchronisation walk's (table, may be null) and the write walk's chained
 // lookup tables (chain, may be null; tw_chain_entry is the definition, shared with the host fill).
-__global__ __launch_bounds__(1024) void k_tw_build(const TwUpload *__restrict__ up, uint32_t n_int, uint16_t *__restrict__ table, uint32_t n_chain,
+__global__ __launch_bounds__(1024) void k_tw_build(const TwUpload *__restrict__ up, uint32_t up_bytes, uint32_t n_int, uint16_t *__restrict__ table, uint32_t n_chain,
                                                    uint64_t *__restrict__ chain, uint32_t *__restrict__ zero16, uint32_t *__restrict__ zero_words, uint32_t n_zero) {
-    __shared__ TwTree tree;
+    // `up` may be pinned HOST memory (no upload in front of this kernel): every workgroup takes its own copy, once
+    __shared__ TwUpload local;
     if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0;  // the decode's flag words
     for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < n_zero; i += gridDim.x * 1024) zero_words[i] = 0;  // the sweep's "published" words
-    for (uint32_t i = threadIdx.x; i < 2 * n_int; i += 1024) tree.child[i] = up->tree.child[i];
+    for (uint32_t i = threadIdx.x; i * 4 < up_bytes; i += 1024) reinterpret_cast<uint32_t *>(&local)[i] = reinterpret_cast<const uint32_t *>(up)[i];
     __syncthreads();
+    const TwTree &tree = local.tree;
     const uint32_t entries = table ? tw_table_entries(n_int) : 0;
     const int16_t *child = tree.child;
     for (uint32_t idx = blockIdx.x * 1024 + threadIdx.x; idx < entries + n_chain; idx += gridDim.x * 1024) {
         if (idx >= entries) {
             const uint32_t i = idx - entries;
             uint32_t t = 0;
-            while (t + 1 < up->plan.n_tables && up->plan.tab[t + 1].first <= i) ++t;
-            chain[i] = tw_chain_entry(&tree, &up->plan, t, i - up->plan.tab[t].first);
+            while (t + 1 < local.plan.n_tables && local.plan.tab[t + 1].first <= i) ++t;
+            chain[i] = tw_chain_entry(&tree, &local.plan, t, i - local.plan.tab[t].first);
             continue;
         }
         const uint32_t r = idx >> 8, f = idx & 255u;
@@ -415,11 +417,11 @@ __global__ __launch_bounds__(256) void k_tw_check(const uint32_t *__restrict__ b
 }
 
 // ---- launch wrappers --------------------------------------------------------------------------------
-void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16,
+void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t up_bytes, uint32_t n_int, uint16_t *table, uint32_t n_chain, uint64_t *chain, uint32_t *zero16,
                      uint32_t *zero_words, uint32_t n_zero) {
     const uint32_t entries = (table ? tw_table_entries(n_int) : 0) + (chain ? n_chain : 0);
     if (!entries) return;
-    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_up, n_int, table, chain ? n_chain : 0u, chain, zero16, zero_words,
+    hipLaunchKernelGGL(k_tw_build, dim3((entries + 1023) / 1024), dim3(1024), 0, stream, d_up, (up_bytes + 3u) & ~3u, n_int, table, chain ? n_chain : 0u, chain, zero16, zero_words,
                        zero_words ? n_zero : 0u);
 }
 
