@@ -75,7 +75,7 @@ struct et_ctx {
     uint32_t *h_lut = nullptr;      // the decode tables being built (one of h_lut_buf)
     uint32_t *h_lut_buf[2] = {};    // DEC_TABLES_BYTES each, used in turn: the host fills one while the other's upload may still be queued
     int lut_turn = 0;
-    uint64_t *h_scalar = nullptr;   // 16: [1] a total, [2..3] flags (range decode), [4..11] the body decode's copy of flag[0..15]
+    uint64_t *h_scalar = nullptr;   // 16: [1] a total, [2..3] flags (range decode), [4..11] the body decode's copy of flag[0..15], [12] / [14] "taken" / "done" words the device stores (enc_block_epoch, header_epoch)
 
     // link between et_histogram_device and et_encode_body_device
     const void *hist_text = nullptr;
@@ -85,6 +85,7 @@ struct et_ctx {
     const void *scan_buf = nullptr;  // the group_sum buffer scan_epoch_n counts on
     size_t scan_cap = 0;
     uint32_t scan_epoch_n = 0;
+    uint64_t enc_block_epoch = 0;  // h_scalar[12] == enc_block_epoch: the device has taken its copy of h_enc
     uint64_t header_epoch = 0;  // h_scalar[14] == header_epoch: the header bytes of the current decode are in h_header
     uint64_t hist_epoch = 0;    // h_hist[256 + w] == hist_epoch: reducing workgroup w of the current histogram has stored its totals
 
@@ -257,6 +258,17 @@ int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) 
 int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *out32, uint64_t base_bit,
              const uint8_t *header, size_t header_len, int ev_scan, int ev_body) {
     const bool long_codes = cb->max_length > 32;
+    // (the pinned block is read by the device itself, K2's first workgroup: not before that has happened for the call
+    // before may it be filled again -- it says so in h_scalar[12]; normally long ago)
+    {
+        volatile const uint64_t *taken = ctx->h_scalar + 12;
+        const double t0 = now_ms();
+        for (uint32_t spin = 0; *taken != ctx->enc_block_epoch; ++spin)
+            if ((spin & 1023u) == 1023u && now_ms() - t0 > 100.0) {
+                ET_HIP(hipStreamSynchronize(ctx->stream));
+                if (*taken != ctx->enc_block_epoch) return fail(ctx, ET_ERR_HIP, "the code table block was never taken");
+            }
+    }
     for (int s = 0; s < 256; ++s) {
         const uint32_t len = cb->length[s];
         uint32_t code = cb->data[s];
@@ -274,9 +286,11 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
         std::memcpy(stage, header, header_len);
         std::memset(stage + header_len, 0, padded - header_len);
     }
-    ET_HIP(hipMemcpyAsync(ctx->enc_table.p, ctx->h_enc, 768 * sizeof(uint32_t) + padded, hipMemcpyHostToDevice, ctx->stream));
-    et::launch_tile_scan(ctx->stream, static_cast<const uint32_t *>(ctx->tile_hist.p), g.n_tiles,
-                         static_cast<const uint32_t *>(ctx->enc_table.p) + 512, static_cast<unsigned long long *>(ctx->tile_bits.p),
+    // (no upload: the code lengths ride in K2's kernel arguments, and its first workgroup copies the pinned block --
+    // code table, lengths, header -- into enc_table for the kernels behind it)
+    et::launch_tile_scan(ctx->stream, static_cast<const uint32_t *>(ctx->tile_hist.p), g.n_tiles, cb->length, ctx->h_enc, static_cast<uint32_t *>(ctx->enc_table.p),
+                         static_cast<uint32_t>(768 + padded / 4), reinterpret_cast<unsigned long long *>(ctx->h_scalar + 12), ++ctx->enc_block_epoch,
+                         static_cast<unsigned long long *>(ctx->tile_bits.p),
                          static_cast<unsigned long long *>(ctx->group_sum.p), scan_epoch(ctx), base_bit,
                          static_cast<unsigned long long *>(ctx->tile_off.p), out32, static_cast<const uint32_t *>(ctx->enc_table.p) + 768,
                          static_cast<uint32_t>(padded / 4));

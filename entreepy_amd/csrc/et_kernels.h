@@ -79,8 +79,11 @@ __host__ __device__ inline uint32_t header_bound(uint8_t d) { return 8u + 6u * (
 // the first min(n, header_bound(d_src[0])) bytes of d_src -> host_dst (pinned host memory, 4-byte aligned, room for that
 // rounded up to 4), then *host_done = epoch (pinned as well)
 void launch_header_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch);
-void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
-                      unsigned long long *tile_bits, unsigned long long *group_sum, uint32_t epoch, unsigned long long base_bit,  // group_sum, epoch: k_scan_fused's pub words (zeroed once) and a value in 1 .. 65535 not used on them since
+// lengths: the 256 code lengths (host memory; they travel as a kernel argument).  host_src / dev_dst / copy_words: a
+// pinned host block the first kernel copies into device memory for the kernels behind it (K4's code table, the header);
+// once it has, it stores taken_epoch into *host_taken (pinned): the block may be filled again.
+void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint8_t *lengths, const uint32_t *host_src, uint32_t *dev_dst,
+                      uint32_t copy_words, unsigned long long *host_taken, unsigned long long taken_epoch, unsigned long long *tile_bits, unsigned long long *group_sum, uint32_t epoch, unsigned long long base_bit,  // group_sum, epoch: k_scan_fused's pub words (zeroed once) and a value in 1 .. 65535 not used on them since
                       unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src = nullptr, uint32_t header_words = 0);  // header_src (device): the file header, copied to out32[0 .. header_words) behind the seam word's zeroing
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32, KernelEvents ev = {});

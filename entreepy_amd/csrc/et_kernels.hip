@@ -266,32 +266,35 @@ __global__ __launch_bounds__(1024) void k_header_to_host(const uint8_t *__restri
 // K2: tile bit totals and their exclusive scan
 // --------------------------------------------------------------------------------
 // One wavefront per tile: lane l holds the code lengths of bins 4l..4l+3 and reads
-// the tile's counts for them with one 16-byte load.
-__global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict__ tile_hist, uint32_t n_tiles,
-                                                     const uint32_t *__restrict__ lengths,
-                                                     unsigned long long *__restrict__ tile_bits) {
+// the tile's counts for them with one 16-byte load.  The lengths arrive as a kernel ARGUMENT (256 bytes), so nothing
+// has to be uploaded in front of this kernel; what the kernels BEHIND it need from the host -- K4's code table, the
+// file header for the scan -- workgroup 0 copies from the pinned block into device memory on the side.
+struct CodeLengths {
+    uint32_t packed[64];  // four lengths per word, symbol 4l in the low byte of word l
+};
+__global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict__ tile_hist, uint32_t n_tiles, const CodeLengths lengths,
+                                                     unsigned long long *__restrict__ tile_bits, const uint32_t *__restrict__ host_src,
+                                                     uint32_t *__restrict__ dev_dst, uint32_t copy_words, unsigned long long *__restrict__ host_taken,
+                                                     unsigned long long epoch) {
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < copy_words; i += BLOCK) dev_dst[i] = host_src[i];
+        __syncthreads();  // (every thread's loads have returned: the host may fill the block again once it sees `epoch`)
+        if (threadIdx.x == 0) __hip_atomic_store(host_taken, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const uint4 len4 = reinterpret_cast<const uint4 *>(lengths)[lane];
+    const uint32_t l4 = lengths.packed[lane];
+    const uint32_t len_x = l4 & 0xffu, len_y = (l4 >> 8) & 0xffu, len_z = (l4 >> 16) & 0xffu, len_w = l4 >> 24;
     for (uint32_t t = wave_global; t < n_tiles; t += n_waves) {
         const uint4 c = reinterpret_cast<const uint4 *>(tile_hist + static_cast<uint64_t>(t) * 256)[lane];
-        unsigned long long s = static_cast<unsigned long long>(c.x) * len4.x + static_cast<unsigned long long>(c.y) * len4.y +
-                               static_cast<unsigned long long>(c.z) * len4.z + static_cast<unsigned long long>(c.w) * len4.w;
+        unsigned long long s = static_cast<unsigned long long>(c.x) * len_x + static_cast<unsigned long long>(c.y) * len_y +
+                               static_cast<unsigned long long>(c.z) * len_z + static_cast<unsigned long long>(c.w) * len_w;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
         if (lane == 0) tile_bits[t] = s;
     }
 }
 
-// Two-level exclusive scan over n values (tile bit totals / workgroup symbol counts):
-// k_scan_local scans groups of 1024 in one workgroup each and leaves the group sums;
-// k_scan_finish adds base + the sums of all earlier groups, writes out[n] = grand
-// total and, for the encoder, zeroes every 32-bit output word that holds a tile
-// boundary: those are the only words two workgroups of K4 may share, and K4 merges
-// into them with atomicOr.
-// verify_state / verify_exit / verify_flag (decode only, else null): the scan's thread i also
-// checks that block i's first subsequence started where block i-1 ended (the "sweep that
-// changes nothing" of the synchronisation, folded in here) and raises *verify_flag if not.
 // Exclusive scan of in[0..n) into out[0..n] (+ base), ONE launch: every group of 1024 scans its own elements, publishes
 // its total and adds up the totals of the groups before it as they appear -- nobody waits for anybody who waits (a
 // group's total needs nothing from outside), groups start in index order, and the words travel as relaxed device-scope
@@ -2343,12 +2346,14 @@ void launch_header_to_host(hipStream_t stream, const void *d_src, uint32_t n, vo
     hipLaunchKernelGGL(k_header_to_host, dim3(1), dim3(1024), 0, stream, static_cast<const uint8_t *>(d_src), n, static_cast<uint32_t *>(host_dst), host_done, epoch);
 }
 
-void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint32_t *lengths,
-                      unsigned long long *tile_bits, unsigned long long *group_sum, uint32_t epoch, unsigned long long base_bit,
+void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint8_t *lengths, const uint32_t *host_src, uint32_t *dev_dst,
+                      uint32_t copy_words, unsigned long long *host_taken, unsigned long long taken_epoch, unsigned long long *tile_bits, unsigned long long *group_sum, uint32_t epoch, unsigned long long base_bit,
                       unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src, uint32_t header_words) {
     uint32_t grid = (n_tiles + 3) / 4;
     if (grid > MAX_GRID) grid = MAX_GRID;
-    hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, lengths, tile_bits);
+    CodeLengths cl;
+    for (int l = 0; l < 64; ++l) cl.packed[l] = lengths[4 * l] | (lengths[4 * l + 1] << 8) | (lengths[4 * l + 2] << 16) | (static_cast<uint32_t>(lengths[4 * l + 3]) << 24);
+    hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, cl, tile_bits, host_src, dev_dst, copy_words, host_taken, taken_epoch);
     const uint32_t groups = (n_tiles + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_fused<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, epoch, base_bit, out32, header_src,
                        header_words, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr),
