@@ -85,12 +85,12 @@ struct et_ctx {
     const void *scan_buf = nullptr;  // the group_sum buffer scan_epoch_n counts on
     size_t scan_cap = 0;
     uint32_t scan_epoch_n = 0;
+    uint32_t report_epoch = 0;     // h_scalar word (4 * 2 + 14) == report_epoch: the current decode's flags and total are in h_flags
     uint64_t enc_block_epoch = 0;  // h_scalar[12] == enc_block_epoch: the device has taken its copy of h_enc
     uint64_t header_epoch = 0;  // h_scalar[14] == header_epoch: the header bytes of the current decode are in h_header
     uint64_t hist_epoch = 0;    // h_hist[256 + w] == hist_epoch: reducing workgroup w of the current histogram has stored its totals
 
     hipEvent_t ev[12] = {};  // 0..5: encode calls, EV_DEC + 0..5: decode calls
-    hipEvent_t ev_flags = nullptr;  // body decode: the sweep flags and the symbol total have reached the host
     et_timings tm_enc = {}, tm_dec = {};
     // A full encode / body decode with timing on leaves its event arithmetic for the first
     // et_last_timings[_of] call (which waits for the call's last event): the call itself
@@ -379,7 +379,6 @@ extern "C" int et_ctx_create(int device, et_ctx **out) {
     // are only being used to measure timing"); with the default flags the ten records of an
     // encode+decode cost ~65 us of cache write-backs and waits at 1 GiB
     for (auto &e : ctx->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableSystemFence) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&ctx->ev_flags, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         et_ctx_destroy(ctx);
         return ET_ERR_HIP;
@@ -405,7 +404,6 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-    if (ctx->ev_flags) (void)hipEventDestroy(ctx->ev_flags);
     if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
     if (ctx->side.fork) (void)hipEventDestroy(ctx->side.fork);
     if (ctx->side.join) (void)hipEventDestroy(ctx->side.join);
@@ -1033,12 +1031,23 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     const uint16_t *tw_table = nullptr;
     const uint64_t *chain = nullptr;      // chained write tables (below)
     uint32_t tw_n_int = 0, n_chain = 0;
+    // the scan's last group stores flags and total into the pinned h_flags and then the launch's epoch into word 14
+    auto wait_report = [&]() -> int {
+        volatile const uint32_t *seen = h_flags + 14;
+        const double w0 = now_ms();
+        for (uint32_t spin = 0; *seen != ctx->report_epoch; ++spin)
+            if ((spin & 1023u) == 1023u && now_ms() - w0 > 200.0) {
+                ET_HIP(hipStreamSynchronize(ctx->stream));
+                if (*seen != ctx->report_epoch) return fail(ctx, ET_ERR_HIP, "the decode's report never reached the host");
+            }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return ET_OK;
+    };
     auto scan_and_total = [&](bool verify) -> int {
         // (the scan's last thread stores the flags and the total straight into the pinned h_flags)
         et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, scan_epoch(ctx), blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
-                            verify ? sub_state : nullptr, blk_exit, flag + 2, first_bit, flag, h_flags);
+                            verify ? sub_state : nullptr, blk_exit, flag + 2, first_bit, flag, h_flags, false, ++ctx->report_epoch);
         ET_HIP(hipGetLastError());
-        ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
         return ET_OK;
     };
     auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
@@ -1075,9 +1084,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     }
     auto scan_and_total_tw = [&]() -> int {
         et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, scan_epoch(ctx), blk_off, reinterpret_cast<unsigned long long *>(flag + 12), blk_start, blk_exit, flag + 2, 0u,
-                            flag, h_flags, true);
+                            flag, h_flags, true, ++ctx->report_epoch);
         ET_HIP(hipGetLastError());
-        ET_HIP(hipEventRecord(ctx->ev_flags, ctx->stream));
         return ET_OK;
     };
     if (!exhaustive) {
@@ -1102,7 +1110,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
             ET_TRY(write_symbols(n_symbols, true));
             wrote = true;
         }
-        ET_HIP(hipEventSynchronize(ctx->ev_flags));  // not the stream: the write kernel keeps running while the caller moves on
+        ET_TRY(wait_report());  // not the stream: the write kernel keeps running while the caller moves on
         exhaustive = static_cast<uint64_t>(h_flags[1]) * 64 > n_blocks;
         more_sweeps = !exhaustive && h_flags[2] != 0;
         if (!et::dec_state_final(h_flags[1], h_flags[2], n_blocks)) wrote = false;  // the speculative launch declined by the same rule
@@ -1146,7 +1154,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     }
     if (exhaustive || more_sweeps) {
         ET_TRY(scan_and_total(false));
-        ET_HIP(hipEventSynchronize(ctx->ev_flags));
+        ET_TRY(wait_report());
     }
     const uint64_t decodable = static_cast<uint64_t>(h_flags[12]) | (static_cast<uint64_t>(h_flags[13]) << 32);
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;

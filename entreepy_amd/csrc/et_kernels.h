@@ -110,8 +110,9 @@ void launch_build_dec_tables(hipStream_t stream, const TablePlan *d_plan, uint32
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum, uint32_t epoch,
                      unsigned long long *blk_off, unsigned long long *total_copy = nullptr, const uint32_t *verify_state = nullptr,
                      const uint32_t *verify_exit = nullptr, uint32_t *verify_flag = nullptr, uint32_t verify_first = 0xffffffffu,
-                     const uint32_t *report_src = nullptr, uint32_t *report_dst = nullptr,  // report_dst: 14 words of pinned host memory (flags 0..11 of report_src, symbol total)
-                     bool verify_rows = false);  // verify_state is the tree walk's blk_start (one row per block) instead of sub_state
+                     const uint32_t *report_src = nullptr, uint32_t *report_dst = nullptr,  // report_dst: 15 words of pinned host memory (flags 0..11 of report_src, symbol total, then report_epoch)
+                     bool verify_rows = false,  // verify_state is the tree walk's blk_start (one row per block) instead of sub_state
+                     uint32_t report_epoch = 0);
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr,

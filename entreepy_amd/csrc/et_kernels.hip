@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void k_scan_fused(const T *__restrict__ in, u
                                                      unsigned long long *__restrict__ total_copy, const uint32_t *__restrict__ verify_state,
                                                      const uint32_t *__restrict__ verify_exit, uint32_t *__restrict__ verify_flag, uint32_t verify_first,
                                                      uint32_t verify_stride, uint32_t verify_mask, const uint32_t *__restrict__ report_src,
-                                                     uint32_t *__restrict__ report_dst) {
+                                                     uint32_t *__restrict__ report_dst, uint32_t report_epoch) {
     __shared__ unsigned long long wsum[16], psum[16];
     __shared__ uint32_t bad_any;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,6 +394,8 @@ __global__ __launch_bounds__(1024) void k_scan_fused(const T *__restrict__ in, u
             report_dst[12] = static_cast<uint32_t>(total);
             report_dst[13] = static_cast<uint32_t>(total >> 32);
             __threadfence_system();
+            // word 14: "the report is there" -- the host polls it (no event behind this kernel, no wake-up)
+            __hip_atomic_store(report_dst + 14, report_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (g == 0 && header_words) {
@@ -2357,7 +2359,7 @@ void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_
     const uint32_t groups = (n_tiles + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_fused<unsigned long long>, dim3(groups), dim3(1024), 0, stream, tile_bits, n_tiles, tile_off, group_sum, epoch, base_bit, out32, header_src,
                        header_words, static_cast<unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr),
-                       static_cast<uint32_t *>(nullptr), 0xffffffffu, 0u, 0u, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr));
+                       static_cast<uint32_t *>(nullptr), 0xffffffffu, 0u, 0u, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), 0u);
 }
 
 void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
@@ -2622,11 +2624,11 @@ void launch_dec_exhaustive(hipStream_t stream, const uint32_t *words, uint64_t n
 
 void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_blocks, unsigned long long *group_sum, uint32_t epoch,
                      unsigned long long *blk_off, unsigned long long *total_copy, const uint32_t *verify_state, const uint32_t *verify_exit,
-                     uint32_t *verify_flag, uint32_t verify_first, const uint32_t *report_src, uint32_t *report_dst, bool verify_rows) {
+                     uint32_t *verify_flag, uint32_t verify_first, const uint32_t *report_src, uint32_t *report_dst, bool verify_rows, uint32_t report_epoch) {
     const uint32_t groups = (n_blocks + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_fused<uint32_t>, dim3(groups), dim3(1024), 0, stream, blk_count, n_blocks, blk_off, group_sum, epoch, 0ull, static_cast<uint32_t *>(nullptr),
                        static_cast<const uint32_t *>(nullptr), 0u, total_copy, verify_state, verify_exit, verify_flag, verify_first,
-                       verify_rows ? 1u : static_cast<uint32_t>(BLOCK), verify_rows ? 0xffffffffu : 0xffu, report_src, report_dst);
+                       verify_rows ? 1u : static_cast<uint32_t>(BLOCK), verify_rows ? 0xffffffffu : 0xffu, report_src, report_dst, report_epoch);
 }
 
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
