@@ -140,6 +140,7 @@ __device__ __forceinline__ Chunk load_chunk_in_tile(const uint8_t *__restrict__ 
 // threads meant 4 wavefronts per SIMD and a latency-bound kernel; 512 threads double the
 // loads in flight on the same LDS: 0.283 -> 0.227 ms at 1 GiB (1024 threads: 0.235).
 constexpr int HIST_BLOCK = 512;
+constexpr uint32_t HIST_ROWS = 1024;  // k_hist_tiles' grid at most: block_hist is [256][HIST_ROWS]
 __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__restrict__ base, uint64_t lo, uint64_t hi,
                                                            uint32_t rounds_per_tile, uint32_t n_tiles,
                                                            uint32_t *__restrict__ tile_hist,
@@ -201,23 +202,29 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__rest
         }
         __syncthreads();
     }
-    if (tid < 256) block_hist[static_cast<uint64_t>(blockIdx.x) * 256 + tid] = acc;
+    // (transposed: column `tid`, row blockIdx.x -- 256 scattered 8-byte stores per workgroup, once, so that the
+    // reducing workgroups read their columns as contiguous rows)
+    if (tid < 256) block_hist[static_cast<uint64_t>(tid) * HIST_ROWS + blockIdx.x] = acc;
 }
 
-// Column sums of block_hist[n_rows][256] into hist[256]: workgroup w OWNS columns 2w and 2w + 1 (one 16-byte load
-// per row and thread), so the totals are plain stores -- no zeroing beforehand, no atomics -- and can go to two places:
-// the device's copy and, for the host's code construction that waits behind this kernel, pinned host memory (no copy
-// command in between).  128 workgroups; the strided rows cost 8 x the 2 MiB in cache lines, which is nothing.
+// Sums of block_hist[256][HIST_ROWS] (one row of n_rows partial counts per byte value) into hist[256]: workgroup w
+// OWNS values 2w and 2w + 1, so the totals are plain stores -- no zeroing beforehand, no atomics -- and can go to two
+// places: the device's copy and, for the host's code construction that waits behind this kernel, pinned host memory
+// (no copy command in between).
 __global__ __launch_bounds__(BLOCK) void k_hist_reduce(const unsigned long long *__restrict__ block_hist, uint32_t n_rows,
                                                        unsigned long long *__restrict__ hist, unsigned long long *__restrict__ host_hist,
                                                        unsigned long long epoch) {
     __shared__ unsigned long long part[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long *row0 = block_hist + static_cast<uint64_t>(2 * blockIdx.x) * HIST_ROWS, *row1 = row0 + HIST_ROWS;
     unsigned long long s0 = 0, s1 = 0;
-    for (uint32_t r = tid; r < n_rows; r += BLOCK) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(block_hist + static_cast<uint64_t>(r) * 256 + 2 * blockIdx.x);
-        s0 += v.x;
-        s1 += v.y;
+#pragma unroll
+    for (uint32_t k = 0; k < HIST_ROWS / BLOCK; ++k) {
+        const uint32_t r = k * BLOCK + tid;
+        if (r < n_rows) {
+            s0 += row0[r];
+            s1 += row1[r];
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
