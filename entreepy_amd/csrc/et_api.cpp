@@ -981,8 +981,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
 
     ctx->range.valid = false;  // shares the workspaces
     const double t0 = now_ms();
-    // Which tables this decode needs.  A full code tree (an encoder's always is) and a stream of more than a few
-    // blocks: the tree walk's table and the chained write tables (et_treewalk.h), both filled by ONE small launch
+    // Which tables this decode needs.  A full code tree (an encoder's always is), whatever the stream's size: the
+    // tree walk's table and the chained write tables (et_treewalk.h), both filled by ONE small launch
     // from the tree -- the lookup tables of the LDS-window / register-window kernels are then built only if the
     // stream turns out to need them (it does not synchronise: exhaustive path).  Otherwise those, up front.
     et::DecodeTables tb{}, tb_write{};
@@ -996,11 +996,11 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     // A (nearly) fixed-length code has nothing to re-synchronise on: do not even try.
     bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
     et::TwUpload *h_up = nullptr;
-    if (n_blocks > 3) {
+    {
         h_up = ctx->h_tw_tree[ctx->tw_turn ^= 1];  // two pinned blocks in turn, as prepare_decode_tables' (this call waits for its flags before it returns)
         if (et::tw_build_tree(cb, &h_up->tree) != ET_OK) h_up = nullptr;
     }
-    const bool tw_sweeps = h_up && !exhaustive && n_blocks >= 16;
+    const bool tw_sweeps = h_up && !exhaustive;
     if (!tw_sweeps) ET_TRY(need_tables(true));
     const double t1 = now_ms();
 
