@@ -812,3 +812,39 @@ def test_chained_write_windows_and_long_codes(ctx):
     d_out = torch.empty(text.size + 64, dtype=torch.uint8, device="cuda")
     assert ctx.decode_body_device(cb, d_body, text.size, d_out) == text.size
     assert d_out[: text.size].cpu().numpy().tobytes() == text.tobytes()
+
+
+def test_scan_epochs_run_out_and_start_again(ctx):
+    """k_scan_fused tells this launch's published group totals from older ones by a 16-bit epoch; after 65535 launches on
+    a context the words are zeroed and the epochs start again.  Many more than that many scans (an encode has one, a
+    decode has one) on one context, all with more than one group in the decode's scan (> 1024 blocks), must keep giving
+    the right bytes -- also across a change of size, which reallocates the words."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    c = E.Context(0)
+    c.use_torch_stream()
+    small = corpus.text_like(30_000, 7)
+    big = corpus.text_like(24_000_000, 8)  # ~14 MB packed: ~1700 blocks, two scan groups; 366 encode tiles
+    want_small, want_big = O.encode(small), O.encode(big)
+    d_small, d_big = torch.from_numpy(small).cuda(), torch.from_numpy(big).cuda()
+    enc = torch.zeros(E.encode_bound(big.size) + 64, dtype=torch.uint8, device="cuda")
+    dec = torch.empty(big.size + 64, dtype=torch.uint8, device="cuda")
+
+    def round_trip(d_text, want, check):
+        m = c.encode_device(d_text, enc)
+        k = c.decode_device(enc[4:m], dec)
+        assert m == len(want) and k == d_text.numel()
+        if check:
+            assert enc[:m].cpu().numpy().tobytes() == want
+            assert torch.equal(dec[:k], d_text)
+
+    round_trip(d_big, want_big, True)
+    for i in range(33_500):  # 67 000 scans
+        round_trip(d_small, want_small, i % 2000 == 0)
+        if i % 4000 == 1:
+            round_trip(d_big, want_big, True)
+    round_trip(d_big, want_big, True)
+    c.close()
