@@ -113,6 +113,8 @@ SIGNATURES = {
     "et_decode_device": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "et_histogram_device": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
     "et_histogram_on_host": (ctypes.c_int, [_vp, _vp]),
+    "et_histogram_host": (ctypes.c_int, [_vp, _vp]),
+    "et_histogram_device_ptr": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_void_p)]),
     "et_build_codebook": (ctypes.c_int, [_vp, _cbp]),
     "et_write_header": (ctypes.c_int, [_cbp, _u64, _vp, _sz, _szp]),
     "et_codebook_bits": (ctypes.c_int, [_cbp, _vp, _u64p]),

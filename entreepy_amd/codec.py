@@ -259,6 +259,12 @@ class Context:
         assert hist.numel() == 256 and hist.element_size() == 8
         _check(N.lib().et_histogram_device(self._h, text.data_ptr(), text.numel(), hist.data_ptr()), self._h)
 
+    def histogram_host(self):
+        """The counts of the last histogram_device call on the host (uint64[256]): waits for them, no copy command."""
+        c = np.zeros(256, dtype=np.uint64)
+        _check(N.lib().et_histogram_host(self._h, c.ctypes.data), self._h)
+        return c
+
     def histogram_on_host(self, counts):
         """The counts of the last histogram_device call, already on the host (uint64[256])."""
         c = np.ascontiguousarray(counts, dtype=np.uint64)

@@ -82,6 +82,7 @@ struct et_ctx {
     size_t hist_n = 0;
     uint32_t hist_rpt = 0, hist_tiles = 0;
     bool hist_on_host = false;  // h_hist holds the counts of hist_text
+    bool hist_empty = false;    // the last et_histogram_device was of an empty text (zeros everywhere, no tiles)
     const void *scan_buf = nullptr;  // the group_sum buffer scan_epoch_n counts on
     size_t scan_cap = 0;
     uint32_t scan_epoch_n = 0;
@@ -247,6 +248,7 @@ int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) 
                     reinterpret_cast<unsigned long long *>(ctx->h_hist), ++ctx->hist_epoch, timed(ctx, 0, 1));  // (the totals land in h_hist too: fetch_histogram only waits)
     ET_HIP(hipGetLastError());
     ctx->hist_text = d_text;
+    ctx->hist_empty = false;
     ctx->hist_n = n;
     ctx->hist_rpt = g.rpt;
     ctx->hist_tiles = g.n_tiles;
@@ -506,16 +508,21 @@ extern "C" int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes) {
 // encode
 // ---------------------------------------------------------------------------------
 extern "C" int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, void *d_hist) {
-    if (!ctx || !d_hist || (n && !d_text)) return ET_ERR_ARG;
+    if (!ctx || (n && !d_text)) return ET_ERR_ARG;
     DeviceGuard guard(ctx->device);
     if (n == 0) {
-        ET_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), ctx->stream));
+        ET_TRY(ensure(ctx, ctx->hist, 256 * sizeof(uint64_t)));
+        ET_HIP(hipMemsetAsync(ctx->hist.p, 0, 256 * sizeof(uint64_t), ctx->stream));
+        if (d_hist) ET_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), ctx->stream));
+        std::memset(ctx->h_hist, 0, 256 * sizeof(uint64_t));
         ctx->hist_text = nullptr;
+        ctx->hist_empty = true;
         return ET_OK;
     }
+    ctx->hist_empty = false;
     const Geometry g = make_geometry(ctx, d_text, n);
     ET_TRY(run_histogram(ctx, d_text, n, g));  // (K1 carries events 0 and 1)
-    ET_HIP(hipMemcpyAsync(d_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_hist) ET_HIP(hipMemcpyAsync(d_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->timing) {
         ET_HIP(hipStreamSynchronize(ctx->stream));
         ctx->tm_enc = et_timings{};
@@ -583,6 +590,26 @@ int encode_shard(et_ctx *ctx, const et_codebook *cb, const void *d_text, size_t 
 }
 
 }  // namespace
+
+extern "C" int et_histogram_host(et_ctx *ctx, uint64_t counts[256]) {
+    if (!ctx || !counts) return ET_ERR_ARG;
+    if (ctx->hist_empty) {  // an empty shard's: zeros
+        std::memset(counts, 0, 256 * sizeof(uint64_t));
+        return ET_OK;
+    }
+    if (!ctx->hist_text) return fail(ctx, ET_ERR_ARG, "no current histogram (et_histogram_device first)");
+    DeviceGuard guard(ctx->device);
+    ET_TRY(fetch_histogram(ctx));
+    std::memcpy(counts, ctx->h_hist, 256 * sizeof(uint64_t));
+    return ET_OK;
+}
+
+extern "C" int et_histogram_device_ptr(et_ctx *ctx, const void **d_hist) {
+    if (!ctx || !d_hist) return ET_ERR_ARG;
+    if (!ctx->hist_text && !ctx->hist_empty) return fail(ctx, ET_ERR_ARG, "no current histogram (et_histogram_device first)");
+    *d_hist = ctx->hist.p;
+    return ET_OK;
+}
 
 extern "C" int et_histogram_on_host(et_ctx *ctx, const uint64_t counts[256]) {
     if (!ctx || !counts) return ET_ERR_ARG;

@@ -78,6 +78,8 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
 __host__ __device__ inline uint32_t header_bound(uint8_t d) { return 8u + 6u * (static_cast<uint32_t>(d) + 1u); }
 // the first min(n, header_bound(d_src[0])) bytes of d_src -> host_dst (pinned host memory, 4-byte aligned, room for that
 // rounded up to 4), then *host_done = epoch (pinned as well)
+// d_src[0 .. n_words) dwords (4-byte aligned) -> host_dst (pinned), then *host_done = epoch (pinned)
+void launch_words_to_host(hipStream_t stream, const void *d_src, uint32_t n_words, void *host_dst, unsigned long long *host_done, unsigned long long epoch);
 void launch_header_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch);
 // lengths: the 256 code lengths (host memory; they travel as a kernel argument).  host_src / dev_dst / copy_words: a
 // pinned host block the first kernel copies into device memory for the kernels behind it (K4's code table, the header);

@@ -269,6 +269,16 @@ __global__ __launch_bounds__(1024) void k_header_to_host(const uint8_t *__restri
     if (threadIdx.x == 0) __hip_atomic_store(host_done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// n_words dwords of device memory into pinned host memory, then `epoch` into *host_done (the gathered histograms of
+// a group encode: the host polls instead of waiting behind a copy command).
+__global__ __launch_bounds__(1024) void k_words_to_host(const uint32_t *__restrict__ src, uint32_t n_words, uint32_t *__restrict__ host_dst,
+                                                        unsigned long long *__restrict__ host_done, unsigned long long epoch) {
+    for (uint32_t w = threadIdx.x; w < n_words; w += 1024) host_dst[w] = src[w];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // --------------------------------------------------------------------------------
 // K2: tile bit totals and their exclusive scan
 // --------------------------------------------------------------------------------
@@ -2350,6 +2360,10 @@ void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t 
     hipLaunchKernelGGL(k_hist_reduce, dim3(128), dim3(BLOCK), 0, stream, block_hist, grid, hist, host_hist, epoch);
 }
 
+
+void launch_words_to_host(hipStream_t stream, const void *d_src, uint32_t n_words, void *host_dst, unsigned long long *host_done, unsigned long long epoch) {
+    hipLaunchKernelGGL(k_words_to_host, dim3(1), dim3(1024), 0, stream, static_cast<const uint32_t *>(d_src), n_words, static_cast<uint32_t *>(host_dst), host_done, epoch);
+}
 
 void launch_header_to_host(hipStream_t stream, const void *d_src, uint32_t n, void *host_dst, unsigned long long *host_done, unsigned long long epoch) {
     hipLaunchKernelGGL(k_header_to_host, dim3(1), dim3(1024), 0, stream, static_cast<const uint8_t *>(d_src), n, static_cast<uint32_t *>(host_dst), host_done, epoch);

@@ -19,10 +19,12 @@
 // (plain host buffers: MPI, gloo, threads ...) or RCCL, which is loaded on first use (no link-time
 // dependency: a host without librccl.so still loads the library).
 #include "entreepy_hip.h"
+#include "et_kernels.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -115,6 +117,7 @@ struct et_group {
 
     // exchange staging: device (RCCL) and pinned host
     void *d_send = nullptr, *d_recv = nullptr;  // 2 KiB / world x 2 KiB
+    uint64_t gather_epoch = 0;                  // (h_send's first word == gather_epoch: the gathered histograms are in h_recv)
     uint8_t *h_send = nullptr, *h_recv = nullptr;
 
     // the plan of the last et_encode_sharded
@@ -240,6 +243,7 @@ int group_alloc(et_group *g) {
     ETG_HIP(hipMalloc(&g->d_send, EXCHANGE_MAX));
     ETG_HIP(hipMalloc(&g->d_recv, EXCHANGE_MAX * g->world));
     ETG_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_send), EXCHANGE_MAX));
+    std::memset(g->h_send, 0, EXCHANGE_MAX);
     ETG_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_recv), EXCHANGE_MAX * g->world));
     return ET_OK;
 }
@@ -330,16 +334,30 @@ extern "C" int et_encode_sharded(et_group *g, const void *d_text, size_t n, void
     const int world = g->world, r = g->rank;
     // (1) local histogram, (2) the one exchange
     std::vector<uint64_t> hists(static_cast<size_t>(world) * 256);
-    ETG_TRY(et_histogram_device(g->ctx, d_text, n, g->d_send));
+    ETG_TRY(et_histogram_device(g->ctx, d_text, n, nullptr));  // (the counts stay in the ctx: on the device, and on their way into pinned host memory)
     const double t0 = now_ms();
     if (g->comm && world > 1) {
-        ETG_NCCL(rccl().AllGather(g->d_send, g->d_recv, 256, ncclUint64, g->comm, s));
-        ETG_HIP(hipMemcpyAsync(g->h_recv, g->d_recv, 2048 * static_cast<size_t>(world), hipMemcpyDeviceToHost, s));
-        ETG_HIP(hipStreamSynchronize(s));
+        // RCCL gathers straight from the ctx's device copy; one small kernel stores the world x 2 KiB into pinned
+        // memory and then a "done" word, which this thread polls (no copy command, no stream wait)
+        const void *d_local = nullptr;
+        ETG_TRY(et_histogram_device_ptr(g->ctx, &d_local));
+        ETG_NCCL(rccl().AllGather(d_local, g->d_recv, 256, ncclUint64, g->comm, s));
+        volatile uint64_t *done = reinterpret_cast<volatile uint64_t *>(g->h_send);  // (h_send is free in this branch)
+        const uint64_t epoch = ++g->gather_epoch;
+        et::launch_words_to_host(s, g->d_recv, 512u * static_cast<uint32_t>(world), g->h_recv,
+                                 const_cast<unsigned long long *>(reinterpret_cast<volatile unsigned long long *>(done)), epoch);
+        ETG_HIP(hipGetLastError());
+        const double w0 = now_ms();
+        for (uint32_t spin = 0; *done != epoch; ++spin)
+            if ((spin & 1023u) == 1023u && now_ms() - w0 > 2000.0) {  // (a collective: another rank may be late)
+                ETG_HIP(hipStreamSynchronize(s));
+                if (*done != epoch) return fail(g, ET_ERR_RCCL, "the gathered histograms never reached the host");
+            }
+        std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(hists.data(), g->h_recv, 2048 * static_cast<size_t>(world));
     } else {
-        ETG_HIP(hipMemcpyAsync(g->h_send, g->d_send, 2048, hipMemcpyDeviceToHost, s));
-        ETG_HIP(hipStreamSynchronize(s));
+        // the local counts are polled out of the ctx's pinned copy (no read-back)
+        ETG_TRY(et_histogram_host(g->ctx, reinterpret_cast<uint64_t *>(g->h_send)));
         if (world == 1) std::memcpy(hists.data(), g->h_send, 2048);
         else if (g->allgather(g->user, g->h_send, hists.data(), 2048) != 0) return fail(g, ET_ERR_RCCL, "the exchange callback failed");
     }

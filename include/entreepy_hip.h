@@ -191,6 +191,13 @@ int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t len,
  * Also leaves per-tile histograms in the ctx for a following et_encode_body_device
  * on the SAME (d_text, n). */
 int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, void *d_hist256_u64);
+/* The same counts on the HOST: the reduction stores them into pinned host memory as it stores them on the device, so
+ * this only waits for that histogram (a poll, no copy command) and copies 2 KiB.  After it the shard encode that
+ * follows needs no et_histogram_on_host.  et_histogram_device may be given d_hist = NULL when only the host wants
+ * the counts; et_histogram_device_ptr: where the ctx itself keeps them on the device (valid until its next
+ * histogram), e.g. as the send buffer of a collective.  ET_ERR_ARG unless a histogram of this ctx is current. */
+int et_histogram_host(et_ctx *ctx, uint64_t counts[256]);
+int et_histogram_device_ptr(et_ctx *ctx, const void **d_hist256_u64);
 /* A caller that already holds the counts et_histogram_device produced for (d_text, n) on the host
  * (a sharded encode reads them back for the exchange anyway) hands them over, and the shard encode
  * that follows does not copy them from the device again.  ET_ERR_ARG unless a histogram of this ctx

@@ -848,3 +848,21 @@ def test_scan_epochs_run_out_and_start_again(ctx):
             round_trip(d_big, want_big, True)
     round_trip(d_big, want_big, True)
     c.close()
+
+
+def test_histogram_host_and_device_copies_agree(ctx):
+    """et_histogram_host (the reduction's stores into pinned memory, polled) and et_histogram_device's device copy are
+    the same counts, numpy's; an empty text gives zeros on both sides."""
+    import torch
+
+    for n in (1, 4095, 1 << 20, 5_000_003):
+        data = corpus.text_like(n, n)
+        d = torch.from_numpy(data).cuda()
+        hist = torch.zeros(256, dtype=torch.int64, device="cuda")
+        ctx.histogram_device(d, hist)
+        want = np.bincount(data, minlength=256).astype(np.uint64)
+        assert np.array_equal(ctx.histogram_host(), want)
+        assert np.array_equal(hist.cpu().numpy().astype(np.uint64), want)
+    hist = torch.ones(256, dtype=torch.int64, device="cuda")
+    ctx.histogram_device(torch.empty(0, dtype=torch.uint8, device="cuda"), hist)
+    assert int(hist.sum()) == 0 and int(ctx.histogram_host().sum()) == 0
