@@ -1080,7 +1080,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
         // speculative: the kernel itself looks at the sweeps' flags and does nothing if the state is not final
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
-                             write_ticket_zero, speculative ? flag : nullptr, timed(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain);
+                             write_ticket_zero, speculative ? flag : nullptr, timed(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain, cb->max_length);
         write_ticket_zero = false;
         ET_HIP(hipGetLastError());
         return ET_OK;

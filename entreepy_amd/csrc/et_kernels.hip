@@ -1979,11 +1979,12 @@ __global__ __launch_bounds__(BLOCK) void k_dec_write_reg(const uint32_t *__restr
 struct ChainWalk {
     uint32_t root_h;  // H at a codeword boundary: the root table's LDS address | (32 - CH_ROOT_BITS) << 24
     uint32_t root_t;  // its address alone
+    bool has_len32;   // the dictionary has a 32-bit code
 };
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
 // MODE 1: positions are LDS addresses - 1 (the whole block fits the stage).  Words whose positions lie 64 or more
-// bits before the subsequence's end use the FAST step: both symbol bytes stored behind one another, whatever the
+// bits before the subsequence's end (32 or more when no code is 32 bits long) use the FAST step: both symbol bytes stored behind one another, whatever the
 // entry holds.  After a one-symbol entry the second slot holds a stray byte, after a no-symbol entry both do -- the
 // lane's own slots: a codeword that BEGINS there is at most 32 bits long, so it ends before the subsequence does,
 // another codeword of this lane begins behind it, and its store (stores of one wavefront reach the LDS in program
@@ -2065,7 +2066,12 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
     CH_WORD_FAST(W[7], W[8])
     CH_WORD_FAST(W[8], W[9])
     CH_WORD_FAST(W[9], W[10])
-    while (CH_G >= 64u) CH_STEP_SAFE(W[10], W[11])  // positions 193..224: a 32-bit code from 224 is the lane's last
+    // positions 193..224: a 32-bit code that begins at 224 is the lane's last, so with such codes about this word is SAFE
+    if (MODE == 1 && !cw.has_len32) {
+        while (CH_G >= 64u) CH_STEP_FAST(W[10], W[11])
+    } else {
+        while (CH_G >= 64u) CH_STEP_SAFE(W[10], W[11])
+    }
     X += 32;
     // the last word: whole-index steps while the lookup's index bits all lie inside the subsequence, then one codeword at a time
     while (CH_G + (H >> 24) >= 96u) CH_STEP_SAFE(W[11], W[12])
@@ -2095,7 +2101,7 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
                                                                    const uint2 *__restrict__ chain, uint32_t n_entries,
                                                                    const uint32_t *__restrict__ sub_state, const unsigned long long *__restrict__ blk_off,
                                                                    uint64_t n_symbols, uint8_t *__restrict__ out, uint32_t *__restrict__ ticket,
-                                                                   const uint32_t *__restrict__ void_flags, uint64_t n_subs) {
+                                                                   const uint32_t *__restrict__ void_flags, uint64_t n_subs, uint32_t max_len) {
     if (void_flags && !dec_state_final(void_flags[1], void_flags[2], n_blocks)) return;  // see k_dec_write_reg
     // LDS: tables | wave totals [2][HALVES][4], ticket | HALVES stages
     uint2 *tab = reinterpret_cast<uint2 *>(dec_smem_raw);
@@ -2113,7 +2119,7 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
         v.y += lds_tab;  // next-table offsets -> LDS addresses
         tab[i] = v;
     }
-    const ChainWalk cw = {lds_tab | ((32u - CH_ROOT_BITS) << 24), lds_tab};
+    const ChainWalk cw = {lds_tab | ((32u - CH_ROOT_BITS) << 24), lds_tab, max_len >= 32};
     uint32_t parity = 0;
     for (;;) {
         __syncthreads();  // tables staged (first trip); everybody is done with the ticket word and the stages
@@ -2655,14 +2661,14 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero,
-                      const uint32_t *void_flags, KernelEvents ev, const uint64_t *chain, uint32_t n_chain) {
+                      const uint32_t *void_flags, KernelEvents ev, const uint64_t *chain, uint32_t n_chain, uint32_t chain_max_len) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     if (chain) {  // every block, one launch, no side lane; `tb` is not looked at
         constexpr int HALVES = 2;  // (1: 0.565 ms per GiB of text, 3: 0.54, against 0.509)
         const uint32_t n_chunks_ch = (n_blocks + CH_CHUNK - 1) / CH_CHUNK;
         const size_t smem_chain = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + (2 * HALVES * 4 + 4) * sizeof(uint32_t) + HALVES * (DEC_STAGE_BYTES + 16);
-        ET_LAUNCH_TIMED(k_dec_write_chain<HALVES>, dim3(decode_grid(k_dec_write_chain<HALVES>, smem_chain, n_chunks_ch, true, BLOCK * HALVES)), dim3(BLOCK * HALVES), smem_chain, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, ticket, void_flags, n_subs);
+        ET_LAUNCH_TIMED(k_dec_write_chain<HALVES>, dim3(decode_grid(k_dec_write_chain<HALVES>, smem_chain, n_chunks_ch, true, BLOCK * HALVES)), dim3(BLOCK * HALVES), smem_chain, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, ticket, void_flags, n_subs, chain_max_len);
         return;
     }
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
