@@ -195,17 +195,21 @@ def main():
         state.update(r)
         state["decoded"] = m
 
-    # Set-up, before the W warm-up steps: the pipeline is run 200 times (a third of a second; the same count on every
-    # rank).  A step hands over to the host twice (the histogram for the code construction, the header for the decode's
-    # tables) and the host answers in ~20 us -- when its clocks and caches are up; on a box that has just been leased
-    # the first hundred steps see 2-3 x that.
-    for _ in range(SETTLE_STEPS):
-        step(False, True)
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    # Set-up, before the W warm-up steps: the round trip is verified once, then the pipeline is run 200 times (a third
+    # of a second; the same count on every rank).  A step hands over to the host twice (the histogram for the code
+    # construction, the header for the decode's tables) and the host answers in ~20 us -- when its clocks and caches
+    # are up; on a box that has just been leased the first hundred steps see 2-3 x that.  The GPU's clocks, too, take
+    # ~15 steps to come back after an idle stretch such as the verification's 0.1 s (the write kernel: 0.59 ms falling
+    # to 0.49, rocprofv3 trace): the verification therefore comes first, and nothing but the required synchronisation
+    # stands between the warm-up steps and the timed region.
+    for _ in range(2):
         step(False, True)
     torch.cuda.synchronize()
     assert state["decoded"] == n and torch.equal(dec[:n], text), "round trip is not the identity"
+    for _ in range(SETTLE_STEPS):
+        step(False, True)
+    for _ in range(args.warmup):
+        step(False, True)
 
     def barrier():
         if world > 1:
@@ -220,6 +224,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     add_decode_timings()  # the last step's
+    assert state["decoded"] == n and torch.equal(dec[:n], text), "round trip of the last timed step is not the identity"
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -254,12 +259,12 @@ def main():
         torch.cuda.empty_cache()
         text2 = corpus.enwik_like_torch(n, 0x5EED0009, dev)
         ph2 = {"hist": 0.0, "enc_scan": 0.0, "enc_body": 0.0, "enc_total": 0.0, "dec_sync_first": 0.0, "dec_body": 0.0, "dec_total": 0.0}
-        reps = 6
-        for i in range(reps + 2):
+        reps, lead = 10, 30  # (30 untimed steps first: the GPU's clocks after the generator's idle stretch, see above)
+        for i in range(reps + lead):
             r2 = pipe.encode_shard(text2, enc, timings=False)
             m2 = pipe.decode_shard(enc, r2, dec)
             te, td = pipe.encode_timings(), ctx.timings("decode")
-            if i >= 2:
+            if i >= lead:
                 for k in ("hist", "enc_scan", "enc_body", "enc_total"):
                     ph2[k] += te[k]
                 ph2["dec_sync_first"] += td["sync_first_ms"]
