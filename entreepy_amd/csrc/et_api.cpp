@@ -241,6 +241,22 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Where a call needs an answer from the GPU before it can go on, a kernel stores the answer into pinned host memory and
+// then `want` into *word, and the calling thread polls that word: no copy command, no completion signal, no wake-up
+// (a stream wait returns ~10 us after the kernel).  After patience_ms without the word -- a stream blocked by somebody
+// else's work, or a fault -- the stream wait takes over and reports.
+template <typename T>
+int wait_for_word(et_ctx *ctx, volatile const T *word, T want, double patience_ms, const char *what) {
+    const double t0 = now_ms();
+    for (uint32_t spin = 0; *word != want; ++spin)
+        if ((spin & 1023u) == 1023u && now_ms() - t0 > patience_ms) {
+            ET_HIP(hipStreamSynchronize(ctx->stream));
+            if (*word != want) return fail(ctx, ET_ERR_HIP, what);
+        }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return ET_OK;
+}
+
 int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) {
     ET_TRY(ensure_encode_ws(ctx, g.n_tiles));
     et::launch_hist(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<uint32_t *>(ctx->tile_hist.p),
@@ -262,15 +278,7 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
     const bool long_codes = cb->max_length > 32;
     // (the pinned block is read by the device itself, K2's first workgroup: not before that has happened for the call
     // before may it be filled again -- it says so in h_scalar[12]; normally long ago)
-    {
-        volatile const uint64_t *taken = ctx->h_scalar + 12;
-        const double t0 = now_ms();
-        for (uint32_t spin = 0; *taken != ctx->enc_block_epoch; ++spin)
-            if ((spin & 1023u) == 1023u && now_ms() - t0 > 100.0) {
-                ET_HIP(hipStreamSynchronize(ctx->stream));
-                if (*taken != ctx->enc_block_epoch) return fail(ctx, ET_ERR_HIP, "the code table block was never taken");
-            }
-    }
+    ET_TRY(wait_for_word<uint64_t>(ctx, ctx->h_scalar + 12, ctx->enc_block_epoch, 100.0, "the code table block was never taken"));
     for (int s = 0; s < 256; ++s) {
         const uint32_t len = cb->length[s];
         uint32_t code = cb->data[s];
@@ -305,23 +313,10 @@ int run_body(et_ctx *ctx, const et_codebook *cb, const Geometry &g, uint32_t *ou
 
 int fetch_histogram(et_ctx *ctx) {
     if (ctx->hist_on_host) return ET_OK;
-    // k_hist_reduce stores the totals into h_hist and, behind them, its workgroups' "done" words: poll those (a
-    // stream wait returns ~10 us after the kernel; this sits between the two halves of every encode).  A kernel that
-    // never gets there (a fault) is left to the stream wait to report.
-    volatile const uint64_t *done = ctx->h_hist + 256;
-    const double t0 = now_ms();
-    for (uint32_t spin = 0;; ++spin) {
-        bool all = true;
-        for (uint32_t w = 0; w < et::HIST_REDUCE_GROUPS; ++w) all = all && done[w] == ctx->hist_epoch;
-        if (all) break;
-        if ((spin & 1023u) == 1023u && now_ms() - t0 > 100.0) {
-            ET_HIP(hipStreamSynchronize(ctx->stream));
-            for (uint32_t w = 0; w < et::HIST_REDUCE_GROUPS; ++w)
-                if (done[w] != ctx->hist_epoch) return fail(ctx, ET_ERR_HIP, "the histogram never reached the host");
-            break;
-        }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
+    // k_hist_reduce stores the totals into h_hist and, behind them, one "done" word per workgroup (this sits between
+    // the two halves of every encode)
+    for (uint32_t w = 0; w < et::HIST_REDUCE_GROUPS; ++w)
+        ET_TRY(wait_for_word<uint64_t>(ctx, ctx->h_hist + 256 + w, ctx->hist_epoch, 100.0, "the histogram never reached the host"));
     ctx->hist_on_host = true;
     return ET_OK;
 }
@@ -1059,17 +1054,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     const uint64_t *chain = nullptr;      // chained write tables (below)
     uint32_t tw_n_int = 0, n_chain = 0;
     // the scan's last group stores flags and total into the pinned h_flags and then the launch's epoch into word 14
-    auto wait_report = [&]() -> int {
-        volatile const uint32_t *seen = h_flags + 14;
-        const double w0 = now_ms();
-        for (uint32_t spin = 0; *seen != ctx->report_epoch; ++spin)
-            if ((spin & 1023u) == 1023u && now_ms() - w0 > 200.0) {
-                ET_HIP(hipStreamSynchronize(ctx->stream));
-                if (*seen != ctx->report_epoch) return fail(ctx, ET_ERR_HIP, "the decode's report never reached the host");
-            }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return ET_OK;
-    };
+    auto wait_report = [&]() -> int { return wait_for_word<uint32_t>(ctx, h_flags + 14, ctx->report_epoch, 200.0, "the decode's report never reached the host"); };
     auto scan_and_total = [&](bool verify) -> int {
         // (the scan's last thread stores the flags and the total straight into the pinned h_flags)
         et::launch_dec_scan(ctx->stream, blk_count, n_blocks, group_sum, scan_epoch(ctx), blk_off, reinterpret_cast<unsigned long long *>(flag + 12),
@@ -1398,15 +1383,7 @@ extern "C" int et_decode_device(et_ctx *ctx, const void *d_compressed, size_t le
     const uint64_t epoch = ++ctx->header_epoch;
     et::launch_header_to_host(ctx->stream, d_compressed, static_cast<uint32_t>(head), hdr_data, const_cast<unsigned long long *>(reinterpret_cast<volatile unsigned long long *>(done)), epoch);
     ET_HIP(hipGetLastError());
-    {
-        const double t0 = now_ms();
-        for (uint32_t spin = 0; *done != epoch; ++spin)
-            if ((spin & 1023u) == 1023u && now_ms() - t0 > 100.0) {
-                ET_HIP(hipStreamSynchronize(ctx->stream));
-                if (*done != epoch) return fail(ctx, ET_ERR_HIP, "the header never reached the host");
-            }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
+    ET_TRY(wait_for_word<uint64_t>(ctx, done, epoch, 100.0, "the header never reached the host"));
     et_codebook cb;
     uint64_t n_symbols = 0;
     size_t body_offset = 0;
