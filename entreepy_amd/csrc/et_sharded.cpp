@@ -117,7 +117,7 @@ struct et_group {
 
     // exchange staging: device (RCCL) and pinned host
     void *d_send = nullptr, *d_recv = nullptr;  // 2 KiB / world x 2 KiB
-    uint64_t gather_epoch = 0;                  // (h_send's first word == gather_epoch: the gathered histograms are in h_recv)
+    uint64_t gather_epoch = 0;                  // (the word behind h_send == gather_epoch: the gathered histograms are in h_recv)
     uint8_t *h_send = nullptr, *h_recv = nullptr;
 
     // the plan of the last et_encode_sharded
@@ -242,8 +242,8 @@ namespace {
 int group_alloc(et_group *g) {
     ETG_HIP(hipMalloc(&g->d_send, EXCHANGE_MAX));
     ETG_HIP(hipMalloc(&g->d_recv, EXCHANGE_MAX * g->world));
-    ETG_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_send), EXCHANGE_MAX));
-    std::memset(g->h_send, 0, EXCHANGE_MAX);
+    ETG_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_send), EXCHANGE_MAX + 8));  // (+ the gather's "done" word)
+    std::memset(g->h_send, 0, EXCHANGE_MAX + 8);
     ETG_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_recv), EXCHANGE_MAX * g->world));
     return ET_OK;
 }
@@ -342,7 +342,7 @@ extern "C" int et_encode_sharded(et_group *g, const void *d_text, size_t n, void
         const void *d_local = nullptr;
         ETG_TRY(et_histogram_device_ptr(g->ctx, &d_local));
         ETG_NCCL(rccl().AllGather(d_local, g->d_recv, 256, ncclUint64, g->comm, s));
-        volatile uint64_t *done = reinterpret_cast<volatile uint64_t *>(g->h_send);  // (h_send is free in this branch)
+        volatile uint64_t *done = reinterpret_cast<volatile uint64_t *>(g->h_send + EXCHANGE_MAX);  // (a word of its own behind the exchange buffer)
         const uint64_t epoch = ++g->gather_epoch;
         et::launch_words_to_host(s, g->d_recv, 512u * static_cast<uint32_t>(world), g->h_recv,
                                  const_cast<unsigned long long *>(reinterpret_cast<volatile unsigned long long *>(done)), epoch);
