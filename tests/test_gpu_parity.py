@@ -866,3 +866,83 @@ def test_histogram_host_and_device_copies_agree(ctx):
     hist = torch.ones(256, dtype=torch.int64, device="cuda")
     ctx.histogram_device(torch.empty(0, dtype=torch.uint8, device="cuda"), hist)
     assert int(hist.sum()) == 0 and int(ctx.histogram_host().sum()) == 0
+
+
+def test_polled_hand_overs_fall_back_to_a_stream_wait(ctx):
+    """The calls poll pinned words for the histogram, the header and the decode's report; when the stream is held up by
+    somebody else's work for longer than their patience (0.1 - 0.2 s) they fall back to a stream wait and still
+    deliver: half a second of matrix products is put in front of an encode and of a decode on the same stream."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    c = E.Context(0)
+    c.use_torch_stream()
+    data = corpus.text_like(3_000_000, 61)
+    want = O.encode(data)
+    text = torch.from_numpy(data).cuda()
+    enc = torch.zeros(E.encode_bound(data.size) + 64, dtype=torch.uint8, device="cuda")
+    dec = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+    a = torch.randn(8192, 8192, device="cuda")
+
+    def hold_the_stream():
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        x = a
+        for _ in range(120):
+            x = (x @ a) * 1e-2
+        t1.record()
+        return t0, t1
+
+    t0, t1 = hold_the_stream()
+    m = c.encode_device(text, enc)  # its histogram arrives long after the poll's patience
+    assert t0.elapsed_time(t1) > 150.0, "the stream was not held long enough to exercise the fallback"
+    assert enc[:m].cpu().numpy().tobytes() == want
+    t0, t1 = hold_the_stream()
+    k = c.decode_device(enc[4:m], dec)
+    assert t0.elapsed_time(t1) > 150.0
+    assert k == data.size and torch.equal(dec[:k], text)
+    c.close()
+
+
+def test_two_contexts_on_two_threads(ctx):
+    """Contexts are independent: two host threads, each with its own context and stream, encode and decode different
+    texts at the same time; every result equals the oracle's."""
+    import threading
+
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    texts = [corpus.text_like(2_500_000, 71), corpus.enwik_like(2_000_000, 72)]
+    wants = [O.encode(t) for t in texts]
+    errors = []
+
+    def worker(i):
+        try:
+            c = E.Context(0)
+            d = torch.from_numpy(texts[i]).cuda()
+            enc = torch.zeros(E.encode_bound(texts[i].size) + 64, dtype=torch.uint8, device="cuda")
+            dec = torch.empty(texts[i].size + 64, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(40):
+                m = c.encode_device(d, enc)
+                k = c.decode_device(enc[4:m], dec)
+                assert m == len(wants[i]) and k == texts[i].size
+            torch.cuda.synchronize()
+            assert enc[:m].cpu().numpy().tobytes() == wants[i]
+            assert torch.equal(dec[:k], d)
+            c.close()
+        except Exception as e:  # noqa: BLE001 (reported in the main thread)
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in ts)
