@@ -108,6 +108,8 @@ struct et_ctx {
         uint64_t n_bytes = 0, n_subs = 0, total = 0;
         uint32_t n_blocks = 0, flags = 0;
         et::DecodeTables tb = {}, tb_write = {};
+        bool tw = false;  // synchronised by tree walk: the write goes over the chained tables (n_chain entries in ctx->chain_table)
+        uint32_t n_chain = 0, max_len = 0;
         // et_decode_range_maps -> et_decode_range_resolve
         bool maps_valid = false, maps_const = false;
         uint32_t map_stride = 0;
@@ -1202,6 +1204,78 @@ extern "C" int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const vo
     if (n_blocks64 > 0x7fffffffull) return fail(ctx, ET_ERR_ARG, "range too large");
     const uint32_t n_blocks = static_cast<uint32_t>(n_blocks64);
     auto &rs = ctx->range;
+    // A full code tree (an encoder's always is): the sweeps of et_decode_body_device -- k_tw_sync with its seam step,
+    // told that the words in front of the range are stream bytes and that the first lane runs in like any other unless
+    // the caller knows its first bit -- then check + repair launches until no block disagrees with the one before it.
+    // A second call for the same range with the predecessor's exit simply sweeps again from that bit.
+    {
+        et::TwUpload *h_up = ctx->h_tw_tree[ctx->tw_turn ^= 1];
+        if (et::tw_build_tree(cb, &h_up->tree) == ET_OK) {
+            rs.valid = false;
+            et::tw_chain_plan(&h_up->tree, &h_up->plan);
+            ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_start, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_pub, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
+            ET_TRY(ensure(ctx, ctx->worklist, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
+            ET_TRY(ensure(ctx, ctx->tw_table, static_cast<size_t>(et::tw_table_entries(et::TW_MAX_NODES)) * sizeof(uint16_t) + 64));
+            ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
+            ET_TRY(ensure(ctx, ctx->flag, 64));
+            uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p), *blk_exit = static_cast<uint32_t *>(ctx->blk_exit.p);
+            uint32_t *blk_count = static_cast<uint32_t *>(ctx->blk_count.p), *blk_start = static_cast<uint32_t *>(ctx->blk_start.p);
+            uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p), *worklist = static_cast<uint32_t *>(ctx->worklist.p);
+            uint16_t *tw_table = static_cast<uint16_t *>(ctx->tw_table.p);
+            unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
+            uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 2);
+            const uint32_t n_int = h_up->tree.n_int, n_chain = h_up->plan.n_entries;
+            const bool known = in_start_bit >= 0;
+            const uint32_t mode = (has_front ? et::TW_FRONT_OK : 0u) | (known ? 0u : et::TW_START_UNKNOWN);
+            const uint32_t first_bit = known ? static_cast<uint32_t>(in_start_bit) : 0u;
+            et::launch_tw_build(ctx->stream, h_up, static_cast<uint32_t>(et::tw_upload_bytes(h_up)), n_int, tw_table, n_chain, static_cast<uint64_t *>(ctx->chain_table.p), flag,
+                                static_cast<uint32_t *>(ctx->blk_pub.p), n_blocks);
+            et::launch_tw_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tw_table, n_int, sub_state, blk_exit, blk_start, blk_count, flag, et::DEC_FIRST_SWEEP_TRIPS,
+                               nullptr, nullptr, {}, static_cast<uint32_t *>(ctx->blk_pub.p), mode, flag + 9);
+            ET_HIP(hipGetLastError());
+            uint32_t sweeps = 1;
+            for (;;) {  // (normally one look: nothing on the list)
+                ET_HIP(hipMemsetAsync(flag + 8, 0, sizeof(uint32_t), ctx->stream));
+                et::launch_tw_check(ctx->stream, blk_start, blk_exit, n_blocks, worklist, flag + 8, known);
+                ET_HIP(hipMemcpyAsync(h_flags, flag + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                ET_HIP(hipStreamSynchronize(ctx->stream));
+                if (h_flags[0] == 0) break;
+                if (sweeps > n_blocks + 4) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
+                et::launch_tw_sync(ctx->stream, words, n_bytes, first_bit, n_subs, tw_table, n_int, sub_state, blk_exit, blk_start, blk_count, flag, 0xffffffffu, worklist,
+                                   flag + 8, {}, nullptr, mode, flag + 9);
+                ET_HIP(hipGetLastError());
+                ++sweeps;
+            }
+            et::launch_dec_scan(ctx->stream, blk_count, n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), scan_epoch(ctx), blk_off);
+            ET_HIP(hipGetLastError());
+            ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            ET_HIP(hipMemcpyAsync(h_flags, sub_state, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            ET_HIP(hipMemcpyAsync(h_flags + 1, flag + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            ET_HIP(hipStreamSynchronize(ctx->stream));
+            rs.words = words;
+            rs.n_bytes = n_bytes;
+            rs.n_subs = n_subs;
+            rs.n_blocks = n_blocks;
+            rs.total = ctx->h_scalar[1];
+            rs.tw = true;
+            rs.n_chain = n_chain;
+            rs.max_len = cb->max_length;
+            rs.valid = true;
+            info->start_bit = h_flags[0] & 0xffu;
+            info->exit_bit = h_flags[1];
+            info->n_symbols = rs.total;
+            info->sweeps = sweeps;
+            info->reserved = 2;  // tree walk
+            return ET_OK;
+        }
+    }
+    rs.tw = false;
     const bool repair = rs.valid && rs.words == words && rs.n_subs == n_subs && in_start_bit >= 0;
     uint32_t sweeps = 0;
     if (!repair) {
@@ -1277,7 +1351,7 @@ extern "C" int et_decode_range_maps(et_ctx *ctx, const et_codebook *cb, const vo
     if (n_blocks64 > 0x7fffffffull) return fail(ctx, ET_ERR_ARG, "range too large");
     const uint32_t n_blocks = static_cast<uint32_t>(n_blocks64);
     auto &rs = ctx->range;
-    rs.valid = rs.maps_valid = false;
+    rs.valid = rs.maps_valid = rs.tw = false;
     const uint32_t n_starts = cb->max_length;
     const uint32_t stride = n_starts <= 8 ? 8 : (n_starts <= 16 ? 16 : 32);
     const size_t n_groups = (static_cast<size_t>(n_blocks) + 255) / 256;
@@ -1361,7 +1435,8 @@ extern "C" int et_decode_range_write(et_ctx *ctx, uint64_t max_symbols, void *d_
     DeviceGuard guard(ctx->device);
     et::launch_dec_write(ctx->stream, rs.words, rs.n_bytes, rs.n_subs, rs.tb_write, static_cast<const uint32_t *>(ctx->sub_state.p),
                          static_cast<const unsigned long long *>(ctx->blk_off.p), n_out, static_cast<uint8_t *>(d_out),
-                         static_cast<uint32_t *>(ctx->flag.p) + 4);
+                         static_cast<uint32_t *>(ctx->flag.p) + 4, nullptr, false, nullptr, {},
+                         rs.tw ? static_cast<const uint64_t *>(ctx->chain_table.p) : nullptr, rs.n_chain, rs.max_len);
     ET_HIP(hipGetLastError());
     *out_len = static_cast<size_t>(n_out);
     return ET_OK;

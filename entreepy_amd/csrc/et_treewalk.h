@@ -147,9 +147,14 @@ void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t up_bytes
 void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, const uint16_t *table,
                     uint32_t n_int, uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_start, uint32_t *blk_count, uint32_t *changed,
                     uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev = {},
-                    uint32_t *blk_pub = nullptr);  // blk_pub (first sweep; n_blocks words, zeroed): the blocks also settle their seams with the blocks before them (see k_tw_sync)
+                    uint32_t *blk_pub = nullptr, uint32_t mode = 0, uint32_t *exit_bits = nullptr);  // mode / exit_bits: a range of a stream that began earlier (TW_* below).   blk_pub (first sweep; n_blocks words, zeroed): the blocks also settle their seams with the blocks before them (see k_tw_sync)
+// k_tw_sync's mode bits for a RANGE of a stream split over GPUs: the four words in front of `words` are stream bytes;
+// the range's first lane does not know its first bit (it runs in like any other lane, first_bit is ignored).
+// exit_bits (optional): receives the bit offset behind the range's end at which the next codeword begins.
+constexpr uint32_t TW_FRONT_OK = 1, TW_START_UNKNOWN = 2;
 // Blocks whose first lane did not start where the block before ends -> worklist (n_work zeroed by the caller).
-void launch_tw_check(hipStream_t stream, const uint32_t *blk_start, const uint32_t *blk_exit, uint32_t n_blocks, uint32_t *worklist, uint32_t *n_work);
+void launch_tw_check(hipStream_t stream, const uint32_t *blk_start, const uint32_t *blk_exit, uint32_t n_blocks, uint32_t *worklist, uint32_t *n_work,
+                     bool first_known = true);  // first_known = false: block 0 began at an unknown bit (TW_START_UNKNOWN) and is not checked
 
 }  // namespace et
 #endif

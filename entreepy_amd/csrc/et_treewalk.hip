@@ -35,9 +35,10 @@ __device__ __forceinline__ uint32_t tw_wave_inclusive_scan(uint32_t x) {
     return x;
 }
 
-// Word `idx` (may be negative: before `words`) of the stream in host order, zero outside it.
-__device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__restrict__ words, long long idx, uint64_t n_bytes) {
-    if (idx < 0) return 0u;
+// Word `idx` (may be negative: before `words`) of the stream in host order, zero outside it.  front_ok: the four words
+// in front of `words` are stream bytes too (a range of a stream that began earlier).
+__device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__restrict__ words, long long idx, uint64_t n_bytes, bool front_ok) {
+    if (idx < 0) return front_ok && idx >= -4 ? __builtin_bswap32(words[idx]) : 0u;
     const uint64_t b0 = static_cast<uint64_t>(idx) * 4;
     if (b0 + 4 <= n_bytes) return __builtin_bswap32(words[idx]);
     uint32_t v = 0;
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
                                                     uint32_t n_blocks, const uint16_t *__restrict__ table, uint32_t table_entries, uint32_t n_int,
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_start,
                                                     uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed, uint32_t max_trips,
-                                                    const uint32_t *__restrict__ worklist, const uint32_t *__restrict__ n_work, uint32_t *__restrict__ blk_pub) {
+                                                    const uint32_t *__restrict__ worklist, const uint32_t *__restrict__ n_work, uint32_t *__restrict__ blk_pub,
+                                                    uint32_t mode, uint32_t *__restrict__ exit_bits) {
     uint16_t *tab = reinterpret_cast<uint16_t *>(tw_smem);
     const uint32_t T = blockDim.x, tid = threadIdx.x, lane_id = tid & 63;
     const uint32_t n_todo = worklist ? *n_work : n_blocks;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
                 for (int j = 0; j < TW_WORDS; ++j) W[u][j] = __builtin_bswap32(words[w0 + j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < TW_WORDS; ++j) W[u][j] = tw_load_guarded(words, w0 + j, n_bytes);
+                for (int j = 0; j < TW_WORDS; ++j) W[u][j] = tw_load_guarded(words, w0 + j, n_bytes, (mode & TW_FRONT_OK) != 0);
                 // whole bytes of the stream inside the lane's own 64 -> steps that count
                 const uint64_t lane_byte0 = q[u] * 64;
                 limit[u] = static_cast<uint32_t>(n_bytes > lane_byte0 ? (n_bytes - lane_byte0 < 64 ? n_bytes - lane_byte0 : 64) : 0);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
         // or, in a repair sweep, the node the block before ends in.
         const bool first_lane = lane_id == 0;
         bool known_bit = false;
-        if (first_lane && b == 0) {
+        if (first_lane && b == 0 && !(mode & TW_START_UNKNOWN)) {
             known_bit = true;
             skip[0] = first_bit / 8;
             const uint32_t rem = first_bit % 8;
@@ -378,6 +380,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) out_ok[u] = Ct[u] > 0;
         }
+        if (exit_bits && b == n_blocks - 1) {
+            // a range of a stream split over GPUs: where, behind the range's last bit, the next codeword begins -- one past
+            // the first completion seen from the node the range ends in (the word behind the lane is in W; 0 at the root)
+            uint32_t Rx[TW_LANES], Cx[TW_LANES] = {};
+            TwTrack tx;
+#pragma unroll
+            for (int u = 0; u < TW_LANES; ++u) {
+                Rx[u] = r[u].s_out << 9;
+                tx.found[u] = r[u].s_out == 0;
+                tx.start[u] = 0;
+            }
+            tw_walk<640, 4, false, false, true>(W, Rx, Cx, skip, no_limit, 0, tx);
+            if (lane_id == 63) *exit_bits = tx.found[1] ? tx.start[1] : 0u;
+        }
         uint32_t sum = 0;
         const uint32_t next_st0 = __shfl_down(st1[0], 1), next_st1 = __shfl_down(st1[1], 1), first1 = __shfl(st1[1], 0);
 #pragma unroll
@@ -409,9 +425,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
 }
 
 __global__ __launch_bounds__(256) void k_tw_check(const uint32_t *__restrict__ blk_start, const uint32_t *__restrict__ blk_exit, uint32_t n_blocks,
-                                                  uint32_t *__restrict__ worklist, uint32_t *__restrict__ n_work) {
+                                                  uint32_t *__restrict__ worklist, uint32_t *__restrict__ n_work, uint32_t first_known) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= n_blocks) return;
+    if (b >= n_blocks || (b == 0 && !first_known)) return;  // (a range that does not know its first bit: nothing to hold block 0 against)
     const uint32_t want = b ? blk_exit[b - 1] : 0u;  // (the stream's first block starts at a codeword boundary)
     if (blk_start[b] != want) worklist[atomicAdd(n_work, 1u)] = b;
 }
@@ -427,7 +443,7 @@ void launch_tw_build(hipStream_t stream, const TwUpload *d_up, uint32_t up_bytes
 
 void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, const uint16_t *table,
                     uint32_t n_int, uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_start, uint32_t *blk_count, uint32_t *changed,
-                    uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev, uint32_t *blk_pub) {
+                    uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev, uint32_t *blk_pub, uint32_t mode, uint32_t *exit_bits) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t entries = tw_table_entries(n_int);
     const size_t smem = static_cast<size_t>(entries) * 2;
@@ -446,12 +462,12 @@ void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes,
     uint32_t grid = static_cast<uint32_t>(cus) * per_cu;
     if (grid > (n_blocks + waves - 1) / waves) grid = (n_blocks + waves - 1) / waves;
     if (worklist && grid > 64) grid = 64;  // a repair sweep: a handful of blocks (workgroups beyond the list leave at once)
-    if (ev.start || ev.stop) hipExtLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, ev.start, ev.stop, 0, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work, blk_pub);
-    else hipLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work, blk_pub);
+    if (ev.start || ev.stop) hipExtLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, ev.start, ev.stop, 0, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work, blk_pub, mode, exit_bits);
+    else hipLaunchKernelGGL(k_tw_sync, dim3(grid), dim3(threads), smem, stream, words, n_bytes, first_bit, n_subs, n_blocks, table, entries, n_int, sub_state, blk_exit, blk_start, blk_count, changed, max_trips, worklist, n_work, blk_pub, mode, exit_bits);
 }
 
-void launch_tw_check(hipStream_t stream, const uint32_t *blk_start, const uint32_t *blk_exit, uint32_t n_blocks, uint32_t *worklist, uint32_t *n_work) {
-    hipLaunchKernelGGL(k_tw_check, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, blk_start, blk_exit, n_blocks, worklist, n_work);
+void launch_tw_check(hipStream_t stream, const uint32_t *blk_start, const uint32_t *blk_exit, uint32_t n_blocks, uint32_t *worklist, uint32_t *n_work, bool first_known) {
+    hipLaunchKernelGGL(k_tw_check, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, blk_start, blk_exit, n_blocks, worklist, n_work, first_known ? 1u : 0u);
 }
 
 }  // namespace et
