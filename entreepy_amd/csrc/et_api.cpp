@@ -1022,7 +1022,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     et::TwUpload *h_up = nullptr;
     {
         h_up = ctx->h_tw_tree[ctx->tw_turn ^= 1];  // two pinned blocks in turn, as prepare_decode_tables' (this call waits for its flags before it returns)
-        if (et::tw_build_tree(cb, &h_up->tree) != ET_OK) h_up = nullptr;
+        if (et::tw_build_tree(cb, &h_up->tree, true) != ET_OK) h_up = nullptr;  // (bit patterns without a symbol become leaves that decode as byte 0)
     }
     const bool tw_sweeps = h_up && !exhaustive;
     if (!tw_sweeps) ET_TRY(need_tables(true));
@@ -1210,7 +1210,7 @@ extern "C" int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const vo
     // A second call for the same range with the predecessor's exit simply sweeps again from that bit.
     {
         et::TwUpload *h_up = ctx->h_tw_tree[ctx->tw_turn ^= 1];
-        if (et::tw_build_tree(cb, &h_up->tree) == ET_OK) {
+        if (et::tw_build_tree(cb, &h_up->tree, true) == ET_OK) {
             rs.valid = false;
             et::tw_chain_plan(&h_up->tree, &h_up->plan);
             ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));

@@ -36,10 +36,13 @@ struct TwTree {
     int16_t child[2 * TW_MAX_NODES];
 };
 
-// ET_OK when the walk applies: the codes form a FULL binary tree (what an encoder produces; a corrupted
-// dictionary that is still prefix-free may not) of at most TW_MAX_NODES internal nodes with >= 2 leaves.
-// ET_ERR_UNSUPPORTED otherwise: the caller keeps the register-window sweep.
-int tw_build_tree(const et_codebook *cb, TwTree *tree);
+// ET_OK when the codes form a FULL binary tree of at most TW_MAX_NODES internal nodes with >= 2 leaves: what an
+// encoder produces (also under the reference's quirk Q1, whose tree is built without the dropped symbol).  A
+// hand-made dictionary may leave bit patterns without a symbol; complete = true gives every such pattern a leaf of
+// its own that decodes as byte 0 (no stream of a dictionary's own encoder contains one), so that any prefix-free
+// dictionary -- down to a single code -- walks like an encoder's; complete = false turns them away with
+// ET_ERR_UNSUPPORTED, as both do a code that is a prefix of another or is longer than 32 bits.
+int tw_build_tree(const et_codebook *cb, TwTree *tree, bool complete = false);
 // Host fill of the table (rows = n_int + TW_ENTRY_ROWS, 256 entries each): the reference the device's
 // k_tw_build is tested against.
 void tw_fill_table(const TwTree *tree, uint16_t *table);

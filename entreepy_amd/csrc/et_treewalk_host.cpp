@@ -6,8 +6,8 @@
 
 namespace et {
 
-int tw_build_tree(const et_codebook *cb, TwTree *tree) {
-    if (cb->n_coded < 2) return ET_ERR_UNSUPPORTED;
+int tw_build_tree(const et_codebook *cb, TwTree *tree, bool complete) {
+    if (cb->n_coded < (complete ? 1u : 2u)) return ET_ERR_UNSUPPORTED;
     constexpr int16_t NONE = -1;
     tree->n_int = 1;
     tree->pad_ = 0;
@@ -34,7 +34,10 @@ int tw_build_tree(const et_codebook *cb, TwTree *tree) {
         }
     }
     for (uint32_t i = 0; i < 2 * tree->n_int; ++i)
-        if (tree->child[i] == NONE) return ET_ERR_UNSUPPORTED;  // not a full tree (an encoder's always is)
+        if (tree->child[i] == NONE) {
+            if (!complete) return ET_ERR_UNSUPPORTED;  // not a full tree (an encoder's always is)
+            tree->child[i] = TW_LEAF0;  // a code that no symbol has: it decodes as byte 0
+        }
     return ET_OK;
 }
 
