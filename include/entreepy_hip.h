@@ -250,8 +250,9 @@ int et_parse_header(const uint8_t *compressed, size_t len, et_codebook *cb,
 /* decode.zig:143-203 on the GPU: decode up to n_symbols symbols from the bitstream
  * d_body[0..body_bytes) beginning at bit `start_bit` (< 8) of d_body.  `cb` is any prefix-free table with codes of
  * up to 32 bits.  A bit pattern that is no symbol's code cannot occur in a stream of the table's own encoder; in a
- * corrupted one it decodes as byte 0 (the reference spins there, quirk Q6) -- for the hand-made tables that
- * leave such patterns at all; an encoder's tree is full. */
+ * corrupted one it decodes as byte 0 -- or, for tables too sparse for the tree walk (more than 255 internal nodes),
+ * is passed over one bit at a time; the reference spins there (quirk Q6).  Only hand-made tables leave such patterns
+ * at all: an encoder's tree is full. */
 int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body,
                           size_t body_bytes, uint32_t start_bit, uint64_t n_symbols,
                           void *d_out, size_t cap, size_t *out_len);
