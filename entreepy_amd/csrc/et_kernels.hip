@@ -536,10 +536,17 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ET_APPEND(qcode[q], qlen[q]);
             } else if (!__any(wide2)) {
+                // some lane's quad is longer than 32 bits (a long-tailed alphabet: most wavefront rounds have one): that
+                // lane appends that quad as its two pairs, looked up again; everybody else's quads go in whole
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const uint2 e0 = ET_ENTRY(2 * p), e1 = ET_ENTRY(2 * p + 1);
-                    ET_APPEND(e0.x | (e1.x >> (e0.y & 31u)), e0.y + e1.y);
+                for (int q = 0; q < 4; ++q) {
+                    if (qlen[q] <= 32) {
+                        ET_APPEND(qcode[q], qlen[q]);
+                    } else {
+                        const uint2 e0 = ET_ENTRY(4 * q), e1 = ET_ENTRY(4 * q + 1), e2 = ET_ENTRY(4 * q + 2), e3 = ET_ENTRY(4 * q + 3);
+                        ET_APPEND(e0.x | (e1.x >> (e0.y & 31u)), e0.y + e1.y);
+                        ET_APPEND(e2.x | (e3.x >> (e2.y & 31u)), e2.y + e3.y);
+                    }
                 }
             } else {
                 for (int k = 0; k < 16; ++k) {
