@@ -1131,6 +1131,10 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     }
     if (exhaustive) {
         ET_TRY(need_tables(false));
+        // The exhaustive kernels count with the older lookup tables, for which a bit pattern without a symbol is passed
+        // over bit by bit; in the chained tables it is a leaf that decodes as byte 0.  The two agree on every stream of a
+        // FULL tree (an encoder's) -- for a completed one the write has to count like the synchronisation did.
+        if (h_up && h_up->tree.n_int + 1 != cb->n_coded) chain = nullptr;
         if (iters == 0) {  // no first sweep carried the events: plain markers in front of the exhaustive kernels
             record(ctx, EV_DEC + 0);
             record(ctx, EV_DEC + 5);
