@@ -946,3 +946,49 @@ def test_two_contexts_on_two_threads(ctx):
         t.join(120)
     assert not errors, errors
     assert not any(t.is_alive() for t in ts)
+
+
+def test_hand_made_tables_with_codes_nobody_has(ctx):
+    """Dictionaries that leave bit patterns without a symbol (no encoder makes them): a valid stream decodes to its
+    text on every path -- a skewed table (tree walk + chained tables, the patterns become leaves), a flat one (the
+    exhaustive path, which keeps the older write kernel for such trees) -- and a stream that DOES contain the
+    patterns gives bounded output and no fault."""
+    import torch
+
+    import entreepy_amd as E
+
+    rng = np.random.default_rng(123)
+
+    def pack(data_t, len_t, text):
+        lens = len_t[text].astype(np.int64)
+        ends = np.cumsum(lens)
+        total = int(ends[-1])
+        bits = np.zeros(total + 64, dtype=np.uint8)
+        starts = ends - lens
+        for k in range(int(lens.max())):
+            has = lens > k
+            bits[starts[has] + k] = (data_t[text[has]] >> (lens[has] - 1 - k).astype(np.uint32)) & 1
+        return np.packbits(bits[: (total + 7) // 8 * 8])
+
+    # flat: 200 symbols with 8-bit codes 0..199; skewed: codes 0, 10, 110, 1110xxxx (16 of them), pattern 1111.... unused
+    flat_d, flat_l = np.zeros(256, np.uint32), np.zeros(256, np.uint8)
+    flat_d[:200], flat_l[:200] = np.arange(200), 8
+    skew_d, skew_l = np.zeros(256, np.uint32), np.zeros(256, np.uint8)
+    skew_d[65], skew_l[65] = 0b0, 1
+    skew_d[66], skew_l[66] = 0b10, 2
+    skew_d[67], skew_l[67] = 0b110, 3
+    for i in range(16):
+        skew_d[100 + i], skew_l[100 + i] = (0b1110 << 4) | i, 8
+    for data_t, len_t, syms in ((flat_d, flat_l, np.arange(200)), (skew_d, skew_l, np.array([65, 66, 67] + list(range(100, 116))))):
+        cb = E.Codebook.from_tables(data_t, len_t)
+        text = syms[rng.integers(0, syms.size, size=600_000)].astype(np.uint8)
+        body = pack(data_t, len_t, text)
+        d_body = torch.from_numpy(body).cuda()
+        out = torch.empty(text.size + 64, dtype=torch.uint8, device="cuda")
+        assert ctx.decode_body_device(cb, d_body, text.size, out) == text.size
+        assert out[: text.size].cpu().numpy().tobytes() == text.tobytes()
+        # junk: every byte value, so also the patterns no symbol has
+        junk = torch.from_numpy(rng.integers(0, 256, size=body.size, dtype=np.uint8)).cuda()
+        m = ctx.decode_body_device(cb, junk, text.size, out)
+        torch.cuda.synchronize()
+        assert 0 <= m <= text.size
