@@ -151,7 +151,9 @@ def main():
         n = min(n, real.size // world)
         text = torch.from_numpy(real[rank * n : (rank + 1) * n].copy()).to(dev)
         workload_name = f"enwik9 ($ET_CORPUS_ENWIK9): {n} B per GPU"
+        real_sample = real[rank * n : rank * n + min(n, 1 << 30)].copy()  # (the CPU baselines' sample, below)
     else:
+        real_sample = None
         text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev)
         workload_name = (f"text-1G: {n} B per GPU, order-0 samples of a_midsummer_nights_dream.txt's byte distribution "
                          f"(seed 0x5EED0004+rank)")
@@ -255,34 +257,38 @@ def main():
     # shows), same step, a few repetitions -- reported beside the headline, never instead of it.
     second = None
     if world == 1 and not force_group and not args.no_second_workload:
-        del text
-        torch.cuda.empty_cache()
-        text2 = corpus.enwik_like_torch(n, 0x5EED0009, dev)
-        ph2 = {"hist": 0.0, "enc_scan": 0.0, "enc_body": 0.0, "enc_total": 0.0, "dec_sync_first": 0.0, "dec_body": 0.0, "dec_total": 0.0}
-        reps, lead = 10, 30  # (30 untimed steps first: the GPU's clocks after the generator's idle stretch, see above)
-        for i in range(reps + lead):
-            r2 = pipe.encode_shard(text2, enc, timings=False)
-            m2 = pipe.decode_shard(enc, r2, dec)
-            te, td = pipe.encode_timings(), ctx.timings("decode")
-            if i >= lead:
-                for k in ("hist", "enc_scan", "enc_body", "enc_total"):
-                    ph2[k] += te[k]
-                ph2["dec_sync_first"] += td["sync_first_ms"]
-                ph2["dec_body"] += td["body_ms"]
-                ph2["dec_total"] += td["total_ms"]
-        torch.cuda.synchronize()
-        assert m2 == n and torch.equal(dec[:n], text2), "enwik-like round trip is not the identity"
-        cb2 = ctx.last_codebook()
-        p2 = {k: v / reps for k, v in ph2.items()}
-        second = {
-            "workload": f"enwik-like: {n} B, 206 symbols (96 Zipf-like + 110 with probabilities 2^-12 .. 2^-24), seed 0x5EED0009",
-            "symbols": int(cb2.raw.n_coded), "code_lengths": [int(cb2.raw.min_length), int(cb2.raw.max_length)],
-            "packed_bytes": r2["body_bytes"],
-            "encode_GBps": round(n / (p2["enc_total"] * 1e-3) / 1e9, 2), "decode_GBps": round(n / (p2["dec_total"] * 1e-3) / 1e9, 2),
-            "round_trip_GBps": round(n / ((p2["enc_total"] + p2["dec_total"]) * 1e-3) / 1e9, 2),
-            "phase_ms": {k: round(v, 4) for k, v in p2.items()},
-        }
-        text = text2
+        try:  # (beside the headline: whatever goes wrong here is reported in its place and does not cost the line)
+            del text
+            torch.cuda.empty_cache()
+            text2 = corpus.enwik_like_torch(n, 0x5EED0009, dev)
+            ph2 = {"hist": 0.0, "enc_scan": 0.0, "enc_body": 0.0, "enc_total": 0.0, "dec_sync_first": 0.0, "dec_body": 0.0, "dec_total": 0.0}
+            reps, lead = 10, 30  # (30 untimed steps first: the GPU's clocks after the generator's idle stretch, see above)
+            for i in range(reps + lead):
+                r2 = pipe.encode_shard(text2, enc, timings=False)
+                m2 = pipe.decode_shard(enc, r2, dec)
+                te, td = pipe.encode_timings(), ctx.timings("decode")
+                if i >= lead:
+                    for k in ("hist", "enc_scan", "enc_body", "enc_total"):
+                        ph2[k] += te[k]
+                    ph2["dec_sync_first"] += td["sync_first_ms"]
+                    ph2["dec_body"] += td["body_ms"]
+                    ph2["dec_total"] += td["total_ms"]
+            torch.cuda.synchronize()
+            assert m2 == n and torch.equal(dec[:n], text2), "enwik-like round trip is not the identity"
+            cb2 = ctx.last_codebook()
+            p2 = {k: v / reps for k, v in ph2.items()}
+            second = {
+                "workload": f"enwik-like: {n} B, 206 symbols (96 Zipf-like + 110 with probabilities 2^-12 .. 2^-24), seed 0x5EED0009",
+                "symbols": int(cb2.raw.n_coded), "code_lengths": [int(cb2.raw.min_length), int(cb2.raw.max_length)],
+                "packed_bytes": r2["body_bytes"],
+                "encode_GBps": round(n / (p2["enc_total"] * 1e-3) / 1e9, 2), "decode_GBps": round(n / (p2["dec_total"] * 1e-3) / 1e9, 2),
+                "round_trip_GBps": round(n / ((p2["enc_total"] + p2["dec_total"]) * 1e-3) / 1e9, 2),
+                "phase_ms": {k: round(v, 4) for k, v in p2.items()},
+            }
+            text = text2
+        except Exception as e:  # noqa: BLE001
+            second = {"error": repr(e)}
+            torch.cuda.synchronize()
 
     if rank == 0:
         K = args.steps
@@ -351,8 +357,11 @@ def main():
         if second is not None:
             out["workloads"] = {"enwik-like": second}
         if world == 1 and not args.no_cpu_baseline:
-            text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev) if second is not None else text  # the headline stream again
-            host_text = text[: min(n, 1 << 30)].cpu().numpy()
+            if real_sample is not None:
+                host_text = real_sample
+            else:
+                text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev) if second is not None else text  # the headline stream again
+                host_text = text[: min(n, 1 << 30)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host_text[: 768 << 20])
             out["cpu_baseline_parallel"] = cpu_baseline_parallel(host_text, args.cpu_threads)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
