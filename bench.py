@@ -29,7 +29,7 @@ SETTLE_STEPS = 200       # untimed, part of the set-up (see main)
 HBM_COPY_GBPS = 6290.0  # same guide: what a float4 copy reaches (report against both, headline against spec)
 
 
-def cpu_baseline(sample_u8, budget_s=14.0):
+def cpu_baseline(sample_u8, what, budget_s=14.0):
     """Oracle (kind "port": the Zig reference cannot be built here) on one host core,
     on a prefix of the same stream sized to ~budget_s of CPU work."""
     from oracle import oracle as O
@@ -53,12 +53,12 @@ def cpu_baseline(sample_u8, budget_s=14.0):
         "unit": "GB/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {n >> 20} MiB of rank 0's text-1G stream, oracle encode+decode round trip "
+        "sample": f"first {n >> 20} MiB of rank 0's {what} stream, oracle encode+decode round trip "
                   f"(encode {n / (t1 - t0) / 1e6:.1f} MB/s, decode {n / (t2 - t1) / 1e6:.1f} MB/s), 1 thread",
     }
 
 
-def cpu_baseline_parallel(sample_u8, threads, budget_s=8.0):
+def cpu_baseline_parallel(sample_u8, what, threads, budget_s=8.0):
     """SURVEY.md 8d's second CPU figure: the fast chunk-parallel CPU variant
     (oracle/et_cpu_fast.c, one chunk per thread).  Default thread count: this process's
     CPU share of the GPU box (16 host cores per GPU on the pool), not the whole host."""
@@ -83,7 +83,7 @@ def cpu_baseline_parallel(sample_u8, threads, budget_s=8.0):
         "unit": "GB/s",
         "cores": cores,
         "kind": "port-fast",
-        "sample": f"first {n >> 20} MiB of rank 0's text-1G stream, chunk-parallel lookup-table CPU variant, encode+decode "
+        "sample": f"first {n >> 20} MiB of rank 0's {what} stream, chunk-parallel lookup-table CPU variant, encode+decode "
                   f"round trip (encode {n / (t1 - t0) / 1e6:.0f} MB/s, decode {n / (t2 - t1) / 1e6:.0f} MB/s), {cores} threads",
     }
 
@@ -362,8 +362,9 @@ def main():
             else:
                 text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev) if second is not None else text  # the headline stream again
                 host_text = text[: min(n, 1 << 30)].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(host_text[: 768 << 20])
-            out["cpu_baseline_parallel"] = cpu_baseline_parallel(host_text, args.cpu_threads)
+            what = "enwik9" if real_sample is not None else "text-1G"
+            out["cpu_baseline"] = cpu_baseline(host_text[: 768 << 20], what)
+            out["cpu_baseline_parallel"] = cpu_baseline_parallel(host_text, what, args.cpu_threads)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     if world > 1 or force_group:
