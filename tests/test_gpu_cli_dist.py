@@ -402,3 +402,28 @@ def test_cli_refuses_files_without_the_magic(tmp_path, res_files):
     tiny.write_bytes(b"\xe7\xc0")
     r = subprocess.run([EXE, "d", str(tiny), "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+def test_bench_line_has_the_contract_keys():
+    """bench.py as the driver runs it (smaller stream, fewer steps): one JSON line on stdout with the contract's keys,
+    the roofline and CPU-baseline objects, a kernel table that names what a decode really ran, and the second workload."""
+    import json
+    import sys
+
+    env = dict(os.environ, ET_BENCH_BYTES=str(32 << 20))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--cpu-threads", "4"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["unit"] == "GB/s" and d["dtype"] == "u8" and d["value"] > 0
+    assert abs(d["value"] - (32 << 20) / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["kernel"] in d["kernels"] and "k_tw_sync" in d["kernels"] and "k_dec_write_chain" in d["kernels"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    assert "error" not in d["workloads"]["enwik-like"] and d["workloads"]["enwik-like"]["round_trip_GBps"] > 0
