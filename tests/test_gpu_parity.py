@@ -523,7 +523,7 @@ def test_decode_fuzz_dictionaries(ctx):
     assert accepted > 5  # some corrupted tables do remain decodable
 
 
-def test_two_contexts_on_two_threads(ctx):
+def test_two_contexts_on_two_threads_host_pointer_calls(ctx):
     """SURVEY 8b "Threading": the library is thread-safe per et_ctx handle and keeps no hidden
     globals -- two host threads, each with its own context (own stream, workspaces, staging),
     encode and decode different streams at the same time; every result equals the oracle's."""
@@ -907,7 +907,7 @@ def test_polled_hand_overs_fall_back_to_a_stream_wait(ctx):
     c.close()
 
 
-def test_two_contexts_on_two_threads(ctx):
+def test_two_contexts_on_two_threads_device_calls(ctx):
     """Contexts are independent: two host threads, each with its own context and stream, encode and decode different
     texts at the same time; every result equals the oracle's."""
     import threading
