@@ -147,7 +147,29 @@ SIGNATURES = {
     "et_shard_words": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "et_seam_word": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int)]),
     "et_decode_sharded": (ctypes.c_int, [_vp, _vp, _sz, _vp, _sz, _szp, _u64p]),
+    "et_decode_shard_window": (ctypes.c_int, [_vp, _sz, _u64, ctypes.c_int, ctypes.c_int, _u64p, _u64p]),
+    "et_decode_sharded_begin": (ctypes.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, _sz, _u64, _u64p, _u64p]),
+    "et_decode_sharded_write": (ctypes.c_int, [_vp, _vp, _sz, _szp]),
+    "et_group_set_option": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
+    "et_rccl_library": (ctypes.c_char_p, []),
 }
+
+ET_GROUP_FORCE_COLLECTIVES, ET_GROUP_TIMEOUT_MS = 1, 2
+# The entry points of a group (csrc/et_shard_seq.cpp + a backend): what a stand-in library of the CPU tests also exports.
+GROUP_SYMBOLS = ("et_group_create", "et_group_destroy", "et_group_last_error", "et_group_set_option", "et_encode_sharded", "et_shard_merge_seams", "et_shard_write_fd",
+                 "et_shard_place", "et_shard_gather", "et_group_codebook", "et_group_start_bits", "et_group_last_info", "et_decode_sharded", "et_decode_shard_window",
+                 "et_decode_sharded_begin", "et_decode_sharded_write")
+
+
+def declare(L, names=None):
+    """restype / argtypes of the named entry points (default: all) on a loaded library."""
+    for name in names or SIGNATURES:
+        res, args = SIGNATURES[name]
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
 
 _lib = None
 
@@ -168,9 +190,5 @@ def lib():
         except ImportError:
             pass
         L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = declare(L)
     return _lib

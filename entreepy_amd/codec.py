@@ -136,9 +136,15 @@ class Context:
     def __init__(self, device=0):
         self._h = ctypes.c_void_p()
         self.device = device
+        self._groups = []  # weak references to the Groups made on this context: closed before it
         _check(N.lib().et_ctx_create(device, ctypes.byref(self._h)))
 
     def close(self):
+        for ref in self._groups:
+            g = ref()
+            if g is not None:
+                g.close()
+        self._groups = []
         if self._h:
             N.lib().et_ctx_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -332,18 +338,31 @@ class Group:
 
     allgather: callable(bytes of this rank) -> bytes of all ranks in rank order (any transport:
     torch.distributed over gloo, MPI, threads ...), or rccl_id: the 128-byte id rank 0 got from
-    Group.rccl_unique_id(), for an RCCL communicator of the library's own over xGMI."""
+    Group.rccl_unique_id(), for an RCCL communicator of the library's own over xGMI.
 
-    def __init__(self, ctx, rank, world, allgather=None, rccl_id=None):
+    All ranks make the same calls in the same order.  A call in which any rank fails raises on EVERY rank
+    (the rows of each exchange carry the ranks' statuses; include/entreepy_hip.h, "FAILURES").
+
+    lib: the loaded library whose group entry points are called (default: libentreepy_hip.so).  The CPU tests
+    pass a build of the same sequence (csrc/et_shard_seq.cpp) over a stand-in for the GPU."""
+
+    def __init__(self, ctx, rank, world, allgather=None, rccl_id=None, lib=None):
+        import weakref
+
         self.ctx, self.rank, self.world = ctx, rank, world
+        self._lib = lib if lib is not None else N.lib()
         self._h = ctypes.c_void_p()
         self._py_gather = allgather
         self._cb = N.ALLGATHER_FN(self._gather)  # kept alive with the group
+        ctx_h = getattr(ctx, "_h", None)
         if rccl_id is not None:
             ident = (ctypes.c_uint8 * N.ET_RCCL_ID_BYTES).from_buffer_copy(bytes(rccl_id))
-            _check(N.lib().et_group_create_rccl(ctx._h, rank, world, ctypes.byref(ident), ctypes.byref(self._h)), ctx._h)
+            _check(self._lib.et_group_create_rccl(ctx_h, rank, world, ctypes.byref(ident), ctypes.byref(self._h)), ctx_h)
         else:
-            _check(N.lib().et_group_create(ctx._h, rank, world, self._cb if allgather else ctypes.cast(None, N.ALLGATHER_FN), None, ctypes.byref(self._h)), ctx._h)
+            _check(self._lib.et_group_create(ctx_h, rank, world, self._cb if allgather else ctypes.cast(None, N.ALLGATHER_FN), None, ctypes.byref(self._h)),
+                   ctx_h if lib is None else None)
+        if hasattr(ctx, "_groups"):
+            ctx._groups.append(weakref.ref(self))
 
     @staticmethod
     def rccl_unique_id():
@@ -364,14 +383,14 @@ class Group:
     def _ck(self, status):
         if status == N.ET_OK:
             return
-        detail = N.lib().et_group_last_error(self._h).decode()
+        detail = self._lib.et_group_last_error(self._h).decode()
         if status == N.ET_ERR_EMPTY:
             raise EmptyInputError(status, detail)
         raise EntreepyError(status, detail)
 
     def close(self):
         if self._h:
-            N.lib().et_group_destroy(self._h)
+            self._lib.et_group_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -380,51 +399,85 @@ class Group:
         except Exception:
             pass
 
+    def force_collectives(self, on=True):
+        """A group of one takes the transport's path all the same (one-GPU tests of the N > 1 path)."""
+        self._ck(self._lib.et_group_set_option(self._h, N.ET_GROUP_FORCE_COLLECTIVES, int(bool(on))))
+
+    def set_timeout_ms(self, ms):
+        self._ck(self._lib.et_group_set_option(self._h, N.ET_GROUP_TIMEOUT_MS, int(ms)))
+
     @staticmethod
     def _info(i):
         return {k: getattr(i, k) for k, _ in N.ShardInfo._fields_}
 
+    @staticmethod
+    def _ptr(t):
+        return t.data_ptr() if t is not None and t.numel() else None
+
     def encode_sharded(self, text, out):
-        """et_encode_sharded: this rank's chunk (uint8 CUDA tensor, may be empty) -> its piece of the image in `out`."""
+        """et_encode_sharded: this rank's chunk (uint8 tensor, may be empty) -> its piece of the image in `out`."""
         i = N.ShardInfo()
-        self._ck(N.lib().et_encode_sharded(self._h, text.data_ptr() if text.numel() else None, text.numel(), out.data_ptr(), out.numel(), ctypes.byref(i)))
+        self._ck(self._lib.et_encode_sharded(self._h, self._ptr(text), text.numel(), out.data_ptr() if out is not None else None,
+                                             out.numel() if out is not None else 0, ctypes.byref(i)))
         return self._info(i)
 
     def merge_seams(self, out):
-        self._ck(N.lib().et_shard_merge_seams(self._h, out.data_ptr()))
+        self._ck(self._lib.et_shard_merge_seams(self._h, out.data_ptr() if out is not None else None))
 
     def write_fd(self, out, fd):
-        self._ck(N.lib().et_shard_write_fd(self._h, out.data_ptr(), fd))
+        self._ck(self._lib.et_shard_write_fd(self._h, out.data_ptr(), fd))
 
     def place(self, out, image):
-        self._ck(N.lib().et_shard_place(self._h, out.data_ptr(), image.data_ptr(), image.numel()))
+        self._ck(self._lib.et_shard_place(self._h, out.data_ptr(), image.data_ptr(), image.numel()))
 
     def gather(self, out, image, root=0):
-        self._ck(N.lib().et_shard_gather(self._h, out.data_ptr(), image.data_ptr() if image is not None else None,
-                                         image.numel() if image is not None else 0, root))
+        self._ck(self._lib.et_shard_gather(self._h, out.data_ptr(), image.data_ptr() if image is not None else None,
+                                           image.numel() if image is not None else 0, root))
 
     def info(self):
         i = N.ShardInfo()
-        self._ck(N.lib().et_group_last_info(self._h, ctypes.byref(i)))
+        self._ck(self._lib.et_group_last_info(self._h, ctypes.byref(i)))
         return self._info(i)
 
     def codebook(self):
         cb = Codebook()
-        self._ck(N.lib().et_group_codebook(self._h, ctypes.byref(cb.raw)))
+        self._ck(self._lib.et_group_codebook(self._h, ctypes.byref(cb.raw)))
         return cb
 
     def start_bits(self):
         a = np.zeros(self.world + 1, dtype=np.uint64)
-        self._ck(N.lib().et_group_start_bits(self._h, a.ctypes.data))
+        self._ck(self._lib.et_group_start_bits(self._h, a.ctypes.data))
         return [int(x) for x in a]
 
     def decode_sharded(self, compressed_text, out):
         """et_decode_sharded: this rank's block range of one cold stream -> (symbols written, index of the first)."""
         n = ctypes.c_size_t(0)
         first = ctypes.c_uint64(0)
-        self._ck(N.lib().et_decode_sharded(self._h, compressed_text.data_ptr(), compressed_text.numel(), out.data_ptr(), out.numel(),
-                                           ctypes.byref(n), ctypes.byref(first)))
+        self._ck(self._lib.et_decode_sharded(self._h, self._ptr(compressed_text), compressed_text.numel() if compressed_text is not None else 0,
+                                             out.data_ptr() if out is not None else None, out.numel() if out is not None else 0, ctypes.byref(n), ctypes.byref(first)))
         return n.value, first.value
+
+    def decode_window(self, head, length):
+        """et_decode_shard_window: (offset, bytes) of `compressed` this rank needs besides the dictionary (head =
+        the first min(length, 8192) bytes of it, host bytes)."""
+        a, p = _host_u8(head)
+        off, ln = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ck(self._lib.et_decode_shard_window(p, a.size, int(length), self.rank, self.world, ctypes.byref(off), ctypes.byref(ln)))
+        return off.value, ln.value
+
+    def decode_begin(self, head, length, window, window_off, cap=None):
+        """et_decode_sharded_begin (collective): window = uint8 tensor holding bytes [window_off, ...) of `compressed`
+        -> (symbols this rank writes, index of the first)."""
+        a, p = _host_u8(head) if head is not None else (np.zeros(0, dtype=np.uint8), None)
+        n, first = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ck(self._lib.et_decode_sharded_begin(self._h, p, a.size, int(length), self._ptr(window), int(window_off), window.numel() if window is not None else 0,
+                                                   (1 << 64) - 1 if cap is None else int(cap), ctypes.byref(n), ctypes.byref(first)))
+        return n.value, first.value
+
+    def decode_write(self, out):
+        n = ctypes.c_size_t(0)
+        self._ck(self._lib.et_decode_sharded_write(self._h, out.data_ptr() if out is not None else None, out.numel() if out is not None else 0, ctypes.byref(n)))
+        return n.value
 
 
 def shard_words(starts, world, rank):

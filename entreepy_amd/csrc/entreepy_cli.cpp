@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -215,11 +216,16 @@ struct ThreadExchange {
 
 struct RankResult {
     int rc = ET_OK;
+    bool local = false;  // the failure is this rank's own (its text says what happened), not one it heard of in an exchange
     std::string err;
     size_t out_bytes = 0;  // bytes this rank contributed
+    size_t in_bytes = 0;   // bytes of the input file it read
     et_codebook cb = {};
 };
 
+// Every rank makes the same group calls in the same order; the library carries each rank's status in the rows of
+// every exchange, so a rank whose own preparation failed (no memory, a short read) makes its call with nothing to
+// contribute and all ranks return together (include/entreepy_hip.h, "FAILURES").
 int run_sharded(const Options &opt, int in_fd, int out_fd, size_t *in_size, size_t *written, et_codebook *cb_out, std::string *err) {
     struct stat_holder { off_t size; } st{::lseek(in_fd, 0, SEEK_END)};
     if (st.size < 0) { *err = "input is not a regular file"; return ET_ERR_IO; }
@@ -235,78 +241,100 @@ int run_sharded(const Options &opt, int in_fd, int out_fd, size_t *in_size, size
     const size_t skip = compress ? 0 : 4;
     if (!compress && file_size < 9) { *err = "file shorter than its header"; return ET_ERR_FORMAT; }
     *in_size = file_size - skip;
-    for (int r = 0; r < world; ++r) {
+    // contexts and groups first, here: a rank that cannot even join is found before anybody waits for it
+    std::vector<et_ctx *> ctxs(world, nullptr);
+    std::vector<et_group *> grps(world, nullptr);
+    std::vector<std::pair<ThreadExchange *, int>> who(world);
+    int rc0 = ET_OK;
+    for (int r = 0; r < world && rc0 == ET_OK; ++r) {
+        who[r] = {&ex, r};
+        if ((rc0 = et_ctx_create(r % n_dev, &ctxs[r])) != ET_OK) *err = "et_ctx_create";
+        else if ((rc0 = et_group_create(ctxs[r], r, world, ThreadExchange::gather, &who[r], &grps[r])) != ET_OK) *err = "et_group_create";
+    }
+    // a cold stream's header and dictionary: read once, parsed by every rank (decode.zig:34-141)
+    std::vector<uint8_t> head;
+    if (rc0 == ET_OK && !compress) {
+        head.resize(std::min<size_t>(file_size - 4, 8192));
+        if (::pread(in_fd, head.data(), head.size(), 4) != static_cast<ssize_t>(head.size())) { rc0 = ET_ERR_IO; *err = "reading the header"; }  // main.zig:204: text_in[4..]
+    }
+    for (int r = 0; r < world && rc0 == ET_OK; ++r) {
         threads.emplace_back([&, r] {
             RankResult &out = res[r];
-            std::pair<ThreadExchange *, int> who(&ex, r);
-            et_ctx *ctx = nullptr;
-            et_group *grp = nullptr;
+            et_ctx *ctx = ctxs[r];
+            et_group *grp = grps[r];
             void *d_in = nullptr, *d_out = nullptr;
-            auto bail = [&](int rc, const char *what) {
+            auto bail = [&](int rc, const char *what, bool local) {
                 out.rc = rc;
-                out.err = std::string(what) + ": " + (grp && *et_group_last_error(grp) ? et_group_last_error(grp) : (ctx ? et_last_error(ctx) : ""));
+                out.local = local;
+                out.err = std::string(what) + ": " + (*et_group_last_error(grp) ? et_group_last_error(grp) : et_last_error(ctx));
             };
-            const int dev = r % n_dev;
-            int rc = et_ctx_create(dev, &ctx);
-            // (every rank must keep making the same exchanges, so an early failure still walks through them)
-            bool ok = rc == ET_OK;
-            if (!ok) bail(rc, "et_ctx_create");
-            if (ok && (rc = et_group_create(ctx, r, world, ThreadExchange::gather, &who, &grp)) != ET_OK) { bail(rc, "et_group_create"); ok = false; }
-            if (ok) (void)hipSetDevice(dev);
+            (void)hipSetDevice(r % n_dev);
+            int rc = ET_OK;
+            bool ok = true;
             if (compress) {
                 const size_t lo = file_size * r / world, hi = file_size * (r + 1) / world, n = hi - lo;
                 const size_t cap = et_encode_bound(n);
-                if (ok && (hipMalloc(&d_in, n + 16) != hipSuccess || hipMalloc(&d_out, cap + 16) != hipSuccess)) { bail(ET_ERR_NOMEM, "hipMalloc"); ok = false; }
-                if (ok && (rc = et_fd_to_device(ctx, in_fd, lo, n, d_in)) != ET_OK) { bail(rc, "reading the input"); ok = false; }
+                if (hipMalloc(&d_in, n + 16) != hipSuccess || hipMalloc(&d_out, cap + 16) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc", true); ok = false; }
+                if (ok && (rc = et_fd_to_device(ctx, in_fd, lo, n, d_in)) != ET_OK) { bail(rc, "reading the input", true); ok = false; }
+                out.in_bytes = n;
                 et_shard_info info{};
-                if (ok) {
-                    if ((rc = et_encode_sharded(grp, d_in, n, d_out, cap, &info)) != ET_OK) bail(rc, "et_encode_sharded");
-                    else if ((rc = et_shard_merge_seams(grp, d_out)) != ET_OK) bail(rc, "et_shard_merge_seams");
-                    else if (out_fd >= 0 && (rc = et_shard_write_fd(grp, d_out, out_fd)) != ET_OK) bail(rc, "et_shard_write_fd");
-                    if (rc == ET_OK) {
-                        const uint64_t lo_b = info.owned_word_lo * 4, hi_b = std::min<uint64_t>(info.owned_word_hi * 4, info.file_bytes);
-                        out.out_bytes = hi_b > lo_b ? static_cast<size_t>(hi_b - lo_b) : 0;
-                        et_group_codebook(grp, &out.cb);
-                    }
-                } else {  // keep the others from waiting forever on this rank's part of the exchanges
-                    uint8_t zero[2048] = {0};
-                    std::vector<uint8_t> sink(2048 * static_cast<size_t>(world));
-                    ThreadExchange::gather(&who, zero, sink.data(), 2048);
-                    ThreadExchange::gather(&who, zero, sink.data(), 8);
+                // (a rank without its buffers still makes the call: its status travels in its row of the exchange)
+                rc = ok ? et_encode_sharded(grp, d_in, n, d_out, cap, &info) : et_encode_sharded(grp, nullptr, 1, nullptr, 0, &info);
+                if (rc != ET_OK) {
+                    if (ok) bail(rc, "et_encode_sharded", false);
+                } else if ((rc = et_shard_merge_seams(grp, d_out)) != ET_OK) {
+                    bail(rc, "et_shard_merge_seams", false);
+                } else if (out_fd >= 0 && (rc = et_shard_write_fd(grp, d_out, out_fd)) != ET_OK) {
+                    bail(rc, "et_shard_write_fd", true);
+                }
+                if (out.rc == ET_OK) {
+                    const uint64_t lo_b = info.owned_word_lo * 4, hi_b = std::min<uint64_t>(info.owned_word_hi * 4, info.file_bytes);
+                    out.out_bytes = hi_b > lo_b ? static_cast<size_t>(hi_b - lo_b) : 0;
+                    et_group_codebook(grp, &out.cb);
                 }
             } else {
+                // this rank's window of the stream: its 8 KiB-block range with 16 bytes on either side -- not the file
                 const size_t len = file_size - 4;
-                if (ok && hipMalloc(&d_in, len + 32) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc"); ok = false; }
-                if (ok && (rc = et_fd_to_device(ctx, in_fd, 4, len, d_in)) != ET_OK) { bail(rc, "reading the input"); ok = false; }  // main.zig:204: text_in[4..]
-                uint8_t head[9] = {0};
-                size_t n_symbols = 0;
-                if (ok && (::pread(in_fd, head, 9, 0) != 9 || et_decoded_size(head + 4, 5, &n_symbols) != ET_OK)) { bail(ET_ERR_FORMAT, "header"); ok = false; }
-                // a rank's share of the output is at most its share of the blocks' symbols: size for the whole text, lazily
-                if (ok && hipMalloc(&d_out, n_symbols + 64) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc"); ok = false; }
+                uint64_t w_off = 0, w_len = 0;
+                if ((rc = et_decode_shard_window(head.data(), head.size(), len, r, world, &w_off, &w_len)) != ET_OK) { bail(rc, "header", true); ok = false; }
+                if (ok && w_len && hipMalloc(&d_in, w_len + 32) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc", true); ok = false; }
+                if (ok && w_len && (rc = et_fd_to_device(ctx, in_fd, 4 + w_off, w_len, d_in)) != ET_OK) { bail(rc, "reading the input", true); ok = false; }
+                out.in_bytes = ok ? static_cast<size_t>(w_len) : 0;
+                uint64_t n_mine = 0, first = 0;
+                rc = et_decode_sharded_begin(grp, ok ? head.data() : nullptr, head.size(), len, d_in, w_off, static_cast<size_t>(w_len), ~0ull, &n_mine, &first);
                 size_t wrote = 0;
-                uint64_t first = 0;
-                if (ok) {
-                    if ((rc = et_decode_sharded(grp, d_in, len, d_out, n_symbols + 64, &wrote, &first)) != ET_OK) bail(rc, "et_decode_sharded");
-                    else if (out_fd >= 0 && wrote && (rc = et_device_to_fd(ctx, d_out, wrote, out_fd, first)) != ET_OK) bail(rc, "writing the output");
-                    if (rc == ET_OK) out.out_bytes = wrote;
+                if (rc != ET_OK) {
+                    if (ok) bail(rc, "et_decode_sharded", false);
+                } else if (n_mine) {  // the output is sized by the rank's own share, known now
+                    if (hipMalloc(&d_out, n_mine + 64) != hipSuccess) bail(ET_ERR_NOMEM, "hipMalloc", true);
+                    else if ((rc = et_decode_sharded_write(grp, d_out, n_mine + 64, &wrote)) != ET_OK) bail(rc, "et_decode_sharded_write", true);
+                    else if (out_fd >= 0 && wrote && (rc = et_device_to_fd(ctx, d_out, wrote, out_fd, first)) != ET_OK) bail(rc, "writing the output", true);
                 }
+                if (out.rc == ET_OK) out.out_bytes = wrote;
             }
-            if (ctx) (void)hipStreamSynchronize(static_cast<hipStream_t>(et_ctx_stream(ctx)));
+            (void)hipStreamSynchronize(static_cast<hipStream_t>(et_ctx_stream(ctx)));
             if (d_in) (void)hipFree(d_in);
             if (d_out) (void)hipFree(d_out);
-            if (grp) et_group_destroy(grp);
-            if (ctx) et_ctx_destroy(ctx);
         });
     }
     for (auto &t : threads) t.join();
+    for (et_group *g : grps)
+        if (g) et_group_destroy(g);
+    for (et_ctx *c : ctxs)
+        if (c) et_ctx_destroy(c);
+    if (rc0 != ET_OK) return rc0;
     *written = 0;
+    const RankResult *bad = nullptr;
     for (const RankResult &r : res) {
-        if (r.rc != ET_OK) {
-            *err = r.err;
-            return r.rc;
-        }
+        if (r.rc != ET_OK && (!bad || (r.local && !bad->local))) bad = &r;  // (the rank it happened to says it best)
         *written += r.out_bytes;
     }
+    if (bad) {
+        *err = bad->err;
+        return bad->rc;
+    }
+    if (opt.debug && !compress)  // (-d: what each rank read of the input -- the dictionary once, and its own window)
+        for (int r = 0; r < world; ++r) std::printf("rank %d read %zu of %zu bytes\n", r, res[r].in_bytes, file_size - 4);
     *cb_out = res[0].cb;
     return ET_OK;
 }

@@ -259,11 +259,12 @@ int wait_for_word(et_ctx *ctx, volatile const T *word, T want, double patience_m
     return ET_OK;
 }
 
-int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g) {
+int run_histogram(et_ctx *ctx, const void *d_text, size_t n, const Geometry &g, void *d_hist_also = nullptr) {
     ET_TRY(ensure_encode_ws(ctx, g.n_tiles));
     et::launch_hist(ctx->stream, g.base, g.lo, g.hi, g.rpt, g.n_tiles, static_cast<uint32_t *>(ctx->tile_hist.p),
                     static_cast<unsigned long long *>(ctx->block_hist.p), static_cast<unsigned long long *>(ctx->hist.p),
-                    reinterpret_cast<unsigned long long *>(ctx->h_hist), ++ctx->hist_epoch, timed(ctx, 0, 1));  // (the totals land in h_hist too: fetch_histogram only waits)
+                    reinterpret_cast<unsigned long long *>(ctx->h_hist), ++ctx->hist_epoch, timed(ctx, 0, 1),  // (the totals land in h_hist too: fetch_histogram only waits)
+                    static_cast<unsigned long long *>(d_hist_also));
     ET_HIP(hipGetLastError());
     ctx->hist_text = d_text;
     ctx->hist_empty = false;
@@ -327,22 +328,6 @@ int fetch_histogram(et_ctx *ctx) {
 
 // ---------------------------------------------------------------------------------
 extern "C" const char *et_version(void) { return "entreepy-hip 0.1.0 (gfx950; .et format 0x01, reference v1.1.0)"; }
-
-extern "C" const char *et_strerror(int status) {
-    switch (status) {
-        case ET_OK: return "ok";
-        case ET_ERR_EMPTY: return "empty input (error.QueueEmpty)";
-        case ET_ERR_NOMEM: return "out of memory";
-        case ET_ERR_CAP: return "output buffer too small";
-        case ET_ERR_FORMAT: return "malformed .et stream";
-        case ET_ERR_HIP: return "HIP runtime error";
-        case ET_ERR_ARG: return "invalid argument";
-        case ET_ERR_UNSUPPORTED: return "unsupported stream (code length > 32)";
-        case ET_ERR_IO: return "file read/write error";
-        case ET_ERR_RCCL: return "RCCL / exchange failure";
-        default: return "unknown status";
-    }
-}
 
 extern "C" const char *et_last_error(const et_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
 
@@ -518,8 +503,7 @@ extern "C" int et_histogram_device(et_ctx *ctx, const void *d_text, size_t n, vo
     }
     ctx->hist_empty = false;
     const Geometry g = make_geometry(ctx, d_text, n);
-    ET_TRY(run_histogram(ctx, d_text, n, g));  // (K1 carries events 0 and 1)
-    if (d_hist) ET_HIP(hipMemcpyAsync(d_hist, ctx->hist.p, 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    ET_TRY(run_histogram(ctx, d_text, n, g, d_hist));  // (K1 carries events 0 and 1; the reduction stores the totals into d_hist as well: no copy behind it)
     if (ctx->timing) {
         ET_HIP(hipStreamSynchronize(ctx->stream));
         ctx->tm_enc = et_timings{};

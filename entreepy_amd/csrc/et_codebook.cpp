@@ -90,6 +90,23 @@ private:
 
 }  // namespace
 
+// (here, with the rest of the plain host code: every host of the C ABI's status codes links this file)
+extern "C" const char *et_strerror(int status) {
+    switch (status) {
+        case ET_OK: return "ok";
+        case ET_ERR_EMPTY: return "empty input (error.QueueEmpty)";
+        case ET_ERR_NOMEM: return "out of memory";
+        case ET_ERR_CAP: return "output buffer too small";
+        case ET_ERR_FORMAT: return "malformed .et stream";
+        case ET_ERR_HIP: return "HIP runtime error";
+        case ET_ERR_ARG: return "invalid argument";
+        case ET_ERR_UNSUPPORTED: return "unsupported stream (code length > 32)";
+        case ET_ERR_IO: return "file read/write error";
+        case ET_ERR_RCCL: return "RCCL / exchange failure";
+        default: return "unknown status";
+    }
+}
+
 extern "C" int et_build_codebook(const uint64_t hist[256], et_codebook *cb) {
     if (!hist || !cb) return ET_ERR_ARG;
     std::memset(cb, 0, sizeof(*cb));

@@ -72,7 +72,7 @@ struct KernelEvents {
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
                  uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, unsigned long long *host_hist = nullptr, unsigned long long epoch = 0,  // host_hist: 256 + HIST_REDUCE_GROUPS words of pinned host memory: the totals, and per reducing workgroup `epoch` once its two are stored
-                 KernelEvents ev = {});
+                 KernelEvents ev = {}, unsigned long long *hist_also = nullptr);  // hist_also: a second device copy of the totals
 // Bytes that hold the header and the dictionary of a stream whose first byte is d (decode.zig:34: d + 1 entries of at
 // most 8 + 8 + 32 bits behind 5 header bytes), rounded up.
 __host__ __device__ inline uint32_t header_bound(uint8_t d) { return 8u + 6u * (static_cast<uint32_t>(d) + 1u); }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__rest
 // (no copy command in between).
 __global__ __launch_bounds__(BLOCK) void k_hist_reduce(const unsigned long long *__restrict__ block_hist, uint32_t n_rows,
                                                        unsigned long long *__restrict__ hist, unsigned long long *__restrict__ host_hist,
-                                                       unsigned long long epoch) {
+                                                       unsigned long long epoch, unsigned long long *__restrict__ hist_also) {
     __shared__ unsigned long long part[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *row0 = block_hist + static_cast<uint64_t>(2 * blockIdx.x) * HIST_ROWS, *row1 = row0 + HIST_ROWS;
@@ -240,6 +240,10 @@ __global__ __launch_bounds__(BLOCK) void k_hist_reduce(const unsigned long long 
         const unsigned long long t0 = part[0][0] + part[0][1] + part[0][2] + part[0][3], t1 = part[1][0] + part[1][1] + part[1][2] + part[1][3];
         hist[2 * blockIdx.x] = t0;
         hist[2 * blockIdx.x + 1] = t1;
+        if (hist_also) {  // (a second device copy where a caller wants one: the row a group's exchange sends)
+            hist_also[2 * blockIdx.x] = t0;
+            hist_also[2 * blockIdx.x + 1] = t1;
+        }
         if (host_hist) {
             // host_hist[256 ..]: one "these two are there" word per workgroup -- the host polls them instead of waiting
             // for the stream (no completion signal, no wake-up in between)
@@ -2365,12 +2369,13 @@ static uint32_t tile_grid(K kernel, uint32_t n_tiles) {
 }
 
 void launch_hist(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_t hi, uint32_t rounds_per_tile, uint32_t n_tiles,
-                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, unsigned long long *host_hist, unsigned long long epoch, KernelEvents ev) {
+                 uint32_t *tile_hist, unsigned long long *block_hist, unsigned long long *hist, unsigned long long *host_hist, unsigned long long epoch, KernelEvents ev,
+                 unsigned long long *hist_also) {
     // 4 workgroups per CU are resident (LDS): 1024 = one full batch (0.227 ms at 1 GiB; 2048 = two
     // batches 0.231; 1280 or 1536 = a full and a partial batch, 0.32-0.36)
     const uint32_t grid = n_tiles < 1024u ? n_tiles : 1024u;
     ET_LAUNCH_TIMED(k_hist_tiles, dim3(grid), dim3(HIST_BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_hist, block_hist, hist);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(128), dim3(BLOCK), 0, stream, block_hist, grid, hist, host_hist, epoch);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(128), dim3(BLOCK), 0, stream, block_hist, grid, hist, host_hist, epoch, hist_also);
 }
 
 

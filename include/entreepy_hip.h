@@ -313,8 +313,24 @@ int et_group_create(et_ctx *ctx, int rank, int world, et_allgather_fn allgather,
  * ET_ERR_RCCL when librccl.so cannot be loaded or the communicator cannot be made. */
 int et_rccl_unique_id(uint8_t id[ET_RCCL_ID_BYTES]);
 int et_group_create_rccl(et_ctx *ctx, int rank, int world, const uint8_t id[ET_RCCL_ID_BYTES], et_group **group);
-void et_group_destroy(et_group *group);
+void et_group_destroy(et_group *group);  /* (does not touch the group's ctx: either may be destroyed first) */
 const char *et_group_last_error(const et_group *group);
+/* Which RCCL the library bound (the object's name), or why it could not. */
+const char *et_rccl_library(void);
+/* FAILURES.  Every row a rank contributes to an exchange carries its status.  A rank whose local step failed (a
+ * null or too small buffer, a HIP error, a corrupted range) still makes every exchange of the call, and once the
+ * rows are in ALL ranks return the status of the first rank that failed: no rank leaves a collective sequence
+ * early, nobody waits for a rank that has gone.  The reference's error union (encode.zig:25 `!usize`) reaches
+ * every caller.  A failure BEHIND a call's last exchange (an enqueue that failed) is returned by that rank alone
+ * and poisons its group: later calls of that rank only take part in their exchanges, carrying the status, so its
+ * peers hear of it at their next call.  A transport failure (ET_ERR_RCCL: a peer never arrived within the
+ * timeout, the callback failed) ends the call where it is; destroy the group.
+ * Options: ET_GROUP_FORCE_COLLECTIVES (value != 0): a group of ONE takes the transport's path all the same --
+ * the all-gather from device memory, the kernel that hands the rows to the polling host, send/receive to itself in
+ * et_shard_gather -- where it otherwise just copies (one-GPU tests of the N > 1 path).  ET_GROUP_TIMEOUT_MS: how
+ * long an RCCL exchange waits for the other ranks (default 600 000). */
+enum { ET_GROUP_FORCE_COLLECTIVES = 1, ET_GROUP_TIMEOUT_MS = 2 };
+int et_group_set_option(et_group *group, int option, int64_t value);
 
 /* Where this rank's shard sits in the .et image.  Bits and words are counted from the image's first
  * byte; a "word" is 4 bytes.  The rank's buffer holds words [piece_word_lo, piece_word_hi) (word
@@ -333,9 +349,12 @@ typedef struct et_shard_info {
 
 /* encode() (encode.zig:25-337) for one rank's chunk d_text[0..n) of the group's text: local histogram
  * (K1), ONE exchange (all-gather of the 256 x u64 local histograms: their sum is encode.zig:43-47's
- * histogram, each row gives a shard's bit count), the same code table, header and offsets on every rank
- * (et_plan_shards), then the shard's body at its bit offset (K2 + K4).  d_out: 4-byte aligned, cap >=
- * et_encode_bound(n).  A rank may hold no text (n = 0).  ET_ERR_EMPTY when all ranks are empty. */
+ * histogram, each row gives a shard's bit count; the row also carries the rank's status and cap), the same
+ * code table, header and offsets on every rank (et_plan_shards), then the shard's body at its bit offset
+ * (K2 + K4).  d_out: 4-byte aligned, cap >= et_encode_bound(n) -- which holds any shard whose symbols are as
+ * frequent in it as in the whole text; a shard of symbols that are rare elsewhere packs to more, and then ALL
+ * ranks return ET_ERR_CAP (every rank knows every shard's size and cap from the rows).  A rank may hold no text
+ * (n = 0).  ET_ERR_EMPTY when all ranks are empty. */
 int et_encode_sharded(et_group *group, const void *d_text, size_t n, void *d_out, size_t cap, et_shard_info *info);
 /* The bit-offset-adjusted concatenation (encode.zig:319 writes ONE image).  After et_encode_sharded:
  * et_shard_merge_seams -- the owner of a word that several shards share receives their bits (one exchange
@@ -374,6 +393,21 @@ int et_fd_to_device(et_ctx *ctx, int fd, uint64_t file_offset, size_t len, void 
  * self-synchronise exchange their 32-byte exit maps instead. */
 int et_decode_sharded(et_group *group, const void *d_compressed, size_t len, void *d_out, size_t cap, size_t *written,
                       uint64_t *first_index);
+/* The same in two steps, for a rank that holds only what it needs of the stream and sizes its output once it knows
+ * its share.  Offsets count from compressed[0] (the .et file minus its first 4 bytes), which is taken to sit on a
+ * 4-byte boundary; d_compressed above must be 4-byte aligned for the same reason.
+ * et_decode_shard_window: which bytes of `compressed` rank `rank` of `world` needs besides the dictionary -- its
+ *   8 KiB-block range with 16 bytes on either side (window_len 0: the rank holds no blocks); head = the first
+ *   min(len, 8192) bytes of `compressed` in HOST memory (header + dictionary, decode.zig:34-141), len = all of it.
+ * et_decode_sharded_begin (collective): d_window = bytes [window_off, window_off + window_len) of `compressed` in
+ *   device memory (window_off a multiple of 4, d_window 4-byte aligned; at least the window above); cap = symbols
+ *   the rank's output will hold, ~0 when it is sized afterwards.  *n_mine = the symbols this rank writes, the
+ *   first of which is symbol *first_index of the text.
+ * et_decode_sharded_write (rank-local): those symbols into d_out. */
+int et_decode_shard_window(const uint8_t *head, size_t head_len, uint64_t len, int rank, int world, uint64_t *window_off, uint64_t *window_len);
+int et_decode_sharded_begin(et_group *group, const uint8_t *head, size_t head_len, uint64_t len, const void *d_window, uint64_t window_off,
+                            size_t window_len, uint64_t cap, uint64_t *n_mine, uint64_t *first_index);
+int et_decode_sharded_write(et_group *group, void *d_out, size_t cap, size_t *written);
 
 #ifdef __cplusplus
 }

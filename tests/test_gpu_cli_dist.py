@@ -427,3 +427,29 @@ def test_bench_line_has_the_contract_keys():
     assert rf["kernel"] in d["kernels"] and "k_tw_sync" in d["kernels"] and "k_dec_write_chain" in d["kernels"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
     assert "error" not in d["workloads"]["enwik-like"] and d["workloads"]["enwik-like"]["round_trip_GBps"] > 0
+    # the run as the contract words it (W warm-up steps, K timed) is in the line beside the steady-state figure
+    assert d["value_cold"] > 0 and abs(d["value_cold"] - (32 << 20) / (d["ms_per_step_cold"] * 1e-3) / 1e9) < 0.01 * d["value_cold"]
+    assert d["config"]["decode"].startswith("cold")
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher on the command line and no WORLD_SIZE in the environment: bench.py starts
+    the two ranks itself (torch.distributed.run as a child process), relays rank 0's one line and exits 0.  Rehearsed on the
+    box's one GPU: both ranks on cuda:0, rows exchanged over gloo through the library's exchange callback."""
+    import json
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ET_BENCH_BYTES=str(16 << 20), ET_BENCH_DEVICE="0", ET_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--ref-value", "100"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * (16 << 20) / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    for k in ("exchange_ms", "seam_ms", "concat_ms", "scaling_efficiency", "exchange"):
+        assert k in d, k
+    assert abs(d["scaling_efficiency"] - d["value"] / 200.0) < 1e-3
+    assert d["config"]["decode"].startswith("shard ranges with the encode's offsets")

@@ -290,6 +290,129 @@ def test_c_abi_sharded_all_256_symbols_and_flat_codes():
     assert b"".join(p for _, p in sorted(got)) == flat.tobytes()
 
 
+def _statuses(world, body):
+    """body(rank) on `world` threads -> per rank ("ok", value) or ("err", exception); fails if a rank hangs."""
+    out, threads = [None] * world, []
+
+    def wrap(r):
+        try:
+            out[r] = ("ok", body(r))
+        except BaseException as e:  # noqa: BLE001 -- looked at by the caller
+            out[r] = ("err", e)
+
+    for r in range(world):
+        threads.append(threading.Thread(target=wrap, args=(r,)))
+        threads[-1].start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    return out
+
+
+def test_c_abi_a_failing_rank_does_not_strand_the_others(tmp_path):
+    """World 3 on the GPU (rank threads, in-memory exchange): a failure injected on ONE rank -- output buffer too small
+    for its piece, a missing buffer, a corrupt dictionary -- comes back from ALL three calls, for et_encode_sharded,
+    et_shard_merge_seams and et_decode_sharded; nobody is left waiting in an exchange, and the same groups then do a
+    clean encode -> concat -> cold decode that equals the oracle's."""
+    import torch
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+    from entreepy_amd.codec import Group
+    from oracle import oracle as O
+
+    dev = torch.device("cuda", 0)
+    world, n = 3, 900_000
+    data = corpus.text_like(n, 515)
+    want = O.encode(data)
+    cuts = [0, 300_001, 600_002, n]
+    texts = [torch.from_numpy(data[cuts[r] : cuts[r + 1]].copy()).to(dev) for r in range(world)]
+    encs = [torch.full((E.encode_bound(t.numel()) + 64,), 0xFF, dtype=torch.uint8, device=dev) for t in texts]
+    small = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    comp = torch.frombuffer(bytearray(want[4:]), dtype=torch.uint8).to(dev)
+    bad = comp.clone()
+    bad[6] = 0  # the dictionary's first entry: a code of length 0
+    outs = [torch.zeros(n + 64, dtype=torch.uint8, device=dev) for _ in range(world)]
+    tiny = torch.zeros(64, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    x = ThreadGather(world)
+    ctxs = [E.Context(0) for _ in range(world)]
+    groups = [Group(ctxs[r], r, world, allgather=x.of(r)) for r in range(world)]
+
+    def all_failed(res, status, who=None):
+        for r, (kind, e) in enumerate(res):
+            assert kind == "err" and isinstance(e, E.EntreepyError) and e.status == status, (r, kind, e)
+            assert who is None or r == who or f"rank {who}" in str(e), (r, str(e))
+
+    try:
+        all_failed(_statuses(world, lambda r: groups[r].encode_sharded(texts[r], small if r == 1 else encs[r])), N.ET_ERR_CAP, 1)
+        all_failed(_statuses(world, lambda r: groups[r].encode_sharded(texts[r], None if r == 2 else encs[r])), N.ET_ERR_ARG, 2)
+        res = _statuses(world, lambda r: groups[r].encode_sharded(texts[r], encs[r]))
+        assert all(k == "ok" for k, _ in res), res
+        all_failed(_statuses(world, lambda r: groups[r].merge_seams(None if r == 0 else encs[r])), N.ET_ERR_ARG, 0)
+        res = _statuses(world, lambda r: groups[r].merge_seams(encs[r]))
+        assert all(k == "ok" for k, _ in res), res
+        image = torch.zeros((len(want) + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+        for r in range(world):
+            groups[r].place(encs[r], image)
+        torch.cuda.synchronize()
+        assert image[: len(want)].cpu().numpy().tobytes() == want
+        all_failed(_statuses(world, lambda r: groups[r].decode_sharded(comp, tiny if r == 1 else outs[r])), N.ET_ERR_CAP, 1)
+        all_failed(_statuses(world, lambda r: groups[r].decode_sharded(None if r == 0 else comp, outs[r])), N.ET_ERR_ARG, 0)
+        all_failed(_statuses(world, lambda r: groups[r].decode_sharded(bad if r == 2 else comp, outs[r])), N.ET_ERR_FORMAT, 2)
+        res = _statuses(world, lambda r: groups[r].decode_sharded(comp, outs[r]))
+        assert all(k == "ok" for k, _ in res), res
+        torch.cuda.synchronize()
+        pieces = sorted((first, outs[r][:m].cpu().numpy().tobytes()) for r, (_, (m, first)) in enumerate(res))
+        assert b"".join(p for _, p in pieces) == data.tobytes()
+    finally:
+        for c in ctxs:
+            c.close()  # (closes its group first)
+
+
+def test_forced_collectives_run_every_rccl_call_on_one_gpu():
+    """ET_GROUP_FORCE_COLLECTIVES on an RCCL group of ONE: the histogram rows go through ncclAllGather from device memory
+    and the kernel that hands them to the polling host, the seam and cold-decode rows through the generic RCCL exchange,
+    et_shard_gather sends and receives the piece to itself -- the calls an N-GPU run makes, on the one GPU of the box.
+    The image equals the oracle's; the cold decode returns the text."""
+    import torch
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+    from entreepy_amd.codec import Group
+    from oracle import oracle as O
+
+    dev = torch.device("cuda", 0)
+    assert b"rccl" in N.lib().et_rccl_library()
+    with E.Context(0) as c:
+        c.use_torch_stream()
+        g = Group(c, 0, 1, rccl_id=Group.rccl_unique_id())
+        g.force_collectives(True)
+        g.set_timeout_ms(30_000)
+        for data in (corpus.text_like(3_000_001, 41), corpus.uniform(700_000, 72, 1, 201), np.frombuffer(b"hello, world", dtype=np.uint8)):
+            want = O.encode(data)
+            text = torch.from_numpy(data.copy()).to(dev)
+            enc = torch.full((E.encode_bound(data.size) + 64,), 0xFF, dtype=torch.uint8, device=dev)
+            for _ in range(3):  # (the same rows again: the status / cap words stay on the device)
+                i = g.encode_sharded(text, enc)
+            assert i["file_bytes"] == len(want) and i["exchange_ms"] > 0
+            g.merge_seams(enc)
+            image = torch.full(((len(want) + 3) // 4 * 4,), 0xEE, dtype=torch.uint8, device=dev)
+            g.gather(enc, image, 0)
+            torch.cuda.synchronize()
+            assert image[: len(want)].cpu().numpy().tobytes() == want
+            comp = torch.frombuffer(bytearray(want[4:]), dtype=torch.uint8).to(dev)
+            out = torch.zeros(data.size + 64, dtype=torch.uint8, device=dev)
+            m, first = g.decode_sharded(comp, out)
+            torch.cuda.synchronize()
+            assert first == 0 and out[:m].cpu().numpy().tobytes() == data.tobytes()
+        # a failure still reaches the caller through the forced exchange
+        with pytest.raises(E.EntreepyError) as e:
+            g.encode_sharded(text, torch.zeros(4, dtype=torch.uint8, device=dev))
+        assert e.value.status == N.ET_ERR_CAP
+        g.close()
+
+
 def test_cli_gpus_shards_one_file(tmp_path, res_files):
     """`entreepy --gpus N c/d`: one file over N ranks (threads of the CLI; ranks share the box's one GPU) --
     the same bytes as the single-GPU CLI and the oracle, both directions."""
@@ -306,9 +429,13 @@ def test_cli_gpus_shards_one_file(tmp_path, res_files):
         assert et.read_bytes() == want
         assert r.stderr.strip() == f"{O.format_file_size(len(text))} => {O.format_file_size(len(want))}"
         back = tmp_path / f"back{gpus}.txt"
-        r = subprocess.run([EXE, "--gpus", str(gpus), "d", str(et), "-o", str(back)], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([EXE, "--gpus", str(gpus), "-d", "d", str(et), "-o", str(back)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert back.read_bytes() == text
+        # every rank read its own 8 KiB-block range with 16 bytes on either side, not the file (the dictionary is read once, by the process)
+        reads = [int(ln.split()[3]) for ln in r.stdout.splitlines() if ln.startswith("rank ")]
+        assert len(reads) == gpus and all(0 < b <= (len(want) - 4) // gpus + 8192 + 32 for b in reads), reads
+        assert sum(reads) <= len(want) - 4 + 32 * gpus
     # a tiny file: more ranks than bytes worth a word
     small = tmp_path / "small.txt"
     small.write_bytes(res_files["test.txt"])
