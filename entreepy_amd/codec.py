@@ -308,7 +308,8 @@ class Context:
         tail = stream.numel() - end
         _check(N.lib().et_decode_range_sync(self._h, ctypes.byref(codebook.raw), stream.data_ptr() + begin, end - begin, tail,
                                             int(begin >= 16), int(in_start_bit), ctypes.byref(info)), self._h)
-        return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps}
+        return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps,
+                "tree_walk": info.reserved == 2}
 
     def decode_range_maps(self, codebook, stream, begin, end, in_start_bit=-1):
         """Exhaustive variant of decode_range_sync for codes that do not self-synchronise:

@@ -992,3 +992,97 @@ def test_hand_made_tables_with_codes_nobody_has(ctx):
         m = ctx.decode_body_device(cb, junk, text.size, out)
         torch.cuda.synchronize()
         assert 0 <= m <= text.size
+
+
+def _sparse_dictionary():
+    """A prefix-free table no encoder makes: two 2-bit codes and a hundred 16-bit codes 1iiiiiii00000000 -- completed with a
+    leaf for every bit pattern nobody has, its tree has ~900 internal nodes, beyond the tree walk's table (255)."""
+    data_t, len_t = np.zeros(256, np.uint32), np.zeros(256, np.uint8)
+    data_t[32], len_t[32] = 0b00, 2
+    data_t[101], len_t[101] = 0b01, 2
+    for i in range(100):
+        data_t[120 + i], len_t[120 + i] = 0x8000 | (i << 8), 16
+    return data_t, len_t, np.array([32, 101] + list(range(120, 220)))
+
+
+@pytest.mark.parametrize("n", [4_000, 60_000, 2_000_000])
+def test_fallback_sweeps_and_write_are_what_a_sparse_dictionary_runs(ctx, n):
+    """The round-1 kernels are still the decoder of dictionaries outside the tree walk's domain: a whole-stream decode with
+    such a table reports tree_walk_sync = chained_write = False (at the three sizes that pick k_dec_sync / k_dec_write alone,
+    k_dec_sync_reg + k_dec_write_reg, and k_dec_sync_reg2), and returns the text the oracle packed."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    data_t, len_t, syms = _sparse_dictionary()
+    with pytest.raises(E.EntreepyError):  # (not a tree the walk can hold)
+        import ctypes
+
+        from entreepy_amd import _native as N
+
+        k = ctypes.c_uint32(0)
+        E.codec._check(N.lib().et_treewalk_table(ctypes.byref(E.Codebook.from_tables(data_t, len_t).raw), None, 0, ctypes.byref(k)))
+    rng = np.random.default_rng(n)
+    cb = E.Codebook.from_tables(data_t, len_t)
+    text = syms[np.minimum(rng.integers(0, 300, size=n), syms.size - 1) % syms.size].astype(np.uint8)
+    text[rng.random(n) < 0.5] = 32  # half of it the 2-bit code: the stream re-synchronises
+    body, end = O.pack_body(data_t, len_t, text)
+    d_body = torch.from_numpy(np.frombuffer(body, dtype=np.uint8).copy()).cuda()
+    out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    ctx.enable_timing(True)
+    try:
+        assert ctx.decode_body_device(cb, d_body, n, out) == n
+        t = ctx.timings("decode")
+    finally:
+        ctx.enable_timing(False)
+    torch.cuda.synchronize()
+    assert not t["tree_walk_sync"] and not t["chained_write"] and not t["exhaustive_sync"]
+    assert out[:n].cpu().numpy().tobytes() == text.tobytes()
+
+
+def test_fallback_range_sync_is_what_a_sparse_dictionary_runs(ctx):
+    """et_decode_range_sync / _write with the same dictionary: ranges of a split stream take the round-1 sweeps (info says so),
+    a wrong first guess is repaired, and the pieces concatenate to the text."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    data_t, len_t, syms = _sparse_dictionary()
+    cb = E.Codebook.from_tables(data_t, len_t)
+    rng = np.random.default_rng(9)
+    n = 400_000
+    text = syms[rng.integers(0, syms.size, size=n)].astype(np.uint8)
+    text[rng.random(n) < 0.5] = 101
+    body, end = O.pack_body(data_t, len_t, text)
+    stream = torch.from_numpy(np.frombuffer(body, dtype=np.uint8).copy()).cuda()
+    n_blocks = (stream.numel() + 8191) // 8192
+    cuts = [0, (n_blocks // 3) * 8192, (2 * n_blocks // 3) * 8192, stream.numel()]
+    ctxs, infos = [], []
+    for r in range(3):
+        c = E.Context(0)
+        c.use_torch_stream()
+        infos.append(c.decode_range_sync(cb, stream, cuts[r], cuts[r + 1], 0 if r == 0 else -1))
+        assert not infos[-1]["tree_walk"]
+        ctxs.append(c)
+    for _ in range(5):
+        prev, wrong = 0, []
+        for i, inf in enumerate(infos):
+            if inf["start_bit"] != prev:
+                wrong.append((i, prev))
+            prev = inf["exit_bit"]
+        if not wrong:
+            break
+        for i, w in wrong:
+            infos[i] = ctxs[i].decode_range_sync(cb, stream, cuts[i], cuts[i + 1], w)
+    else:
+        raise AssertionError("did not settle")
+    pieces = []
+    for c, inf in zip(ctxs, infos):
+        buf = torch.empty(inf["n_symbols"] + 64, dtype=torch.uint8, device="cuda")
+        m = c.decode_range_write(inf["n_symbols"], buf)
+        torch.cuda.synchronize()
+        pieces.append(buf[:m].cpu().numpy())
+        c.close()
+    assert np.concatenate(pieces)[:n].tobytes() == text.tobytes()

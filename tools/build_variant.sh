@@ -1,0 +1,15 @@
+#!/bin/bash
+# A second build of the library with extra compiler flags, for A/B runs in one tree (ET_LIB_PATH picks it up):
+#   tools/build_variant.sh <name> "<flags>"   ->  variants/libet_<name>.so     (variants/ is git-ignored scratch)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; flags=$2
+out=variants/build_$name
+mkdir -p $out
+HIPCC=/opt/rocm/bin/hipcc
+CXX="-O3 -std=c++17 -fPIC -Iinclude -Ientreepy_amd/csrc $flags"
+for f in et_kernels et_treewalk; do $HIPCC $CXX --offload-arch=gfx950 -c entreepy_amd/csrc/$f.hip -o $out/$f.o & done
+for f in et_treewalk_host et_api et_codebook et_io et_tables et_shard_seq et_shard_hip; do $HIPCC $CXX -c entreepy_amd/csrc/$f.cpp -o $out/$f.o & done
+wait
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o variants/libet_$name.so $out/*.o -lpthread -ldl
+echo "variants/libet_$name.so"
