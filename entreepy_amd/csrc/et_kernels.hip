@@ -174,6 +174,11 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__rest
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
                             const uint32_t sym = (c[u].w[d] >> (8 * b)) & 0xffu;
+#if defined(ET_PROBE_K1_HALF_LANES)  // timing probes (results are wrong): does a ds_add's cost follow its active lanes?
+                            if (tid & 1) continue;
+#elif defined(ET_PROBE_K1_SKIP_SPACE)
+                            if (sym == 0x20u || sym == 0x65u || sym == 0x74u || sym == 0x6fu) continue;
+#endif
                             atomicAdd(mine + sym * 32, 1u);  // ds_add_u32, no return
                         }
                     }
