@@ -2432,7 +2432,11 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32, KernelEvents ev) {
     if (max_len > 32)
         ET_LAUNCH_TIMED(k_encode_tiles_long, dim3(tile_grid(k_encode_tiles_long, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
+#ifdef ET_PROBE_K4_BIG_RING  // timing probe: the 8192-word ring (32 KiB: 4 workgroups per CU instead of 8) for every code table
+    else if (false)
+#else
     else if (max_len <= 31)  // a round emits at most 4096 * 31 / 32 + 2 words: fits a 4096-word ring
+#endif
         ET_LAUNCH_TIMED(k_encode_tiles<4096>, dim3(tile_grid(k_encode_tiles<4096>, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
     else
         ET_LAUNCH_TIMED(k_encode_tiles<8192>, dim3(tile_grid(k_encode_tiles<8192>, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
