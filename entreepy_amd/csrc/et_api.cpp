@@ -1109,9 +1109,6 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
             wrote = true;
         }
         ET_TRY(wait_report());  // not the stream: the write kernel keeps running while the caller moves on
-#ifdef ET_PROBE_IGNORE_SWEEP_FLAGS  // (timing probes whose sweeps give wrong results: no repair, no exhaustive path)
-        h_flags[1] = h_flags[2] = 0;
-#endif
         exhaustive = static_cast<uint64_t>(h_flags[1]) * 64 > n_blocks;
         more_sweeps = !exhaustive && h_flags[2] != 0;
         if (!et::dec_state_final(h_flags[1], h_flags[2], n_blocks)) wrote = false;  // the speculative launch declined by the same rule

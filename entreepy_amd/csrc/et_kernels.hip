@@ -174,11 +174,6 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__rest
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
                             const uint32_t sym = (c[u].w[d] >> (8 * b)) & 0xffu;
-#if defined(ET_PROBE_K1_HALF_LANES)  // timing probes (results are wrong): does a ds_add's cost follow its active lanes?
-                            if (tid & 1) continue;
-#elif defined(ET_PROBE_K1_SKIP_SPACE)
-                            if (sym == 0x20u || sym == 0x65u || sym == 0x74u || sym == 0x6fu) continue;
-#endif
                             atomicAdd(mine + sym * 32, 1u);  // ds_add_u32, no return
                         }
                     }
@@ -568,9 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
 #undef ET_ENTRY
             if (fill) atomicOr(reinterpret_cast<uint32_t *>(ring_bytes + wbyte), part);
             run += round_total;
-#ifndef ET_PROBE_K4_NO_FLUSH_BARRIER  // (timing probe: results are wrong without it)
             __syncthreads();
-#endif
             flush_words<RING_WORDS>(f, flushed, run >> 5);
             flushed = run >> 5;
             cur = nxt;
@@ -1998,7 +1991,6 @@ struct ChainWalk {
     uint32_t root_h;  // H at a codeword boundary: the root table's LDS address | (32 - CH_ROOT_BITS) << 24
     uint32_t root_t;  // its address alone
     bool has_len32;   // the dictionary has a 32-bit code
-    uint32_t probe_stage;  // (timing probes only)
 };
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
@@ -2018,45 +2010,28 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
     uint2 e;
 #define CH_G (X & 1023u)
 #define CH_MID ((H & 0xffffu) != cw.root_t)
-#ifdef ET_PROBE_D3_PRIVATE_READS  // timing probe (results are wrong): every lane's lookups go to its own bank pair
-#define CH_ADDR(w_) ((H & 0xffffu) == cw.root_t ? ((((((w_) >> (H >> 24)) & ~15u) | (threadIdx.x & 15u)) << 3) + (H & 0xffffu)) : ((((w_) >> (H >> 24)) << 3) + (H & 0xffffu)))  /* (the root table only: it has room for it) */
-#else
-#define CH_ADDR(w_) ((((w_) >> (H >> 24)) << 3) + (H & 0xffffu))
-#endif
 #define CH_READ(hi_, lo_)                                                                                        \
     {                                                                                                            \
         const uint32_t w_ = __builtin_amdgcn_alignbit(hi_, lo_, X);                                              \
-        const unsigned long long v_ = *reinterpret_cast<const lds_u64 *>(static_cast<uintptr_t>(CH_ADDR(w_))); \
+        const unsigned long long v_ = *reinterpret_cast<const lds_u64 *>(static_cast<uintptr_t>(((w_ >> (H >> 24)) << 3) + (H & 0xffffu))); \
         e.x = static_cast<uint32_t>(v_);                                                                         \
         e.y = static_cast<uint32_t>(v_ >> 32);                                                                   \
     }
 #define CH_ADV X += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(e.x)))
-#ifdef ET_PROBE_D3_PRIVATE_STORES  // timing probe (results are wrong): every lane's stores go to its own bank
-#define CH_PUT1(slot_, v_) *reinterpret_cast<lds_u8 *>(static_cast<uintptr_t>(cw.probe_stage + ((threadIdx.x & 31u) << 2) + (((slot_) + 1u) & 3u) + ((((slot_) + 1u) >> 2) & 63u) * 128u)) = static_cast<uint8_t>(v_)
-#else
 #define CH_PUT1(slot_, v_) *reinterpret_cast<lds_u8 *>(static_cast<uintptr_t>((slot_) + 1u)) = static_cast<uint8_t>(v_)
-#endif
 #define CH_PUT2(slot_, v_)                                                                   \
     {                                                                                        \
         const uint32_t q_ = (slot_);                                                         \
         if (q_ - lo < hi - lo) smem8[stage_off + (q_ - lo)] = static_cast<uint8_t>(v_);       \
     }
-#if defined(ET_PROBE_D3_NO_STORES)  // timing probes (results are wrong): the fast step without its byte stores / with one of them
-#define CH_FAST_PUTS(p0_)
-#elif defined(ET_PROBE_D3_ONE_STORE)
-#define CH_FAST_PUTS(p0_) CH_PUT1(p0_, e.x >> 16);
-#else
-#define CH_FAST_PUTS(p0_)         \
-    CH_PUT1(p0_, e.x >> 16);      \
-    CH_PUT1(p0_ + 1u, e.y >> 16);
-#endif
 #define CH_STEP_FAST(hi_, lo_)           \
     {                                    \
         CH_READ(hi_, lo_)                \
         H = e.y;                         \
         const uint32_t p0_ = X >> 10;    \
         CH_ADV;                          \
-        CH_FAST_PUTS(p0_)                \
+        CH_PUT1(p0_, e.x >> 16);         \
+        CH_PUT1(p0_ + 1u, e.y >> 16);    \
     }
 #define CH_STEP_SAFE(hi_, lo_)                                                              \
     {                                                                                       \
@@ -2121,12 +2096,10 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
 #undef CH_STEP_ONE
 #undef CH_STEP_SAFE
 #undef CH_STEP_FAST
-#undef CH_FAST_PUTS
 #undef CH_PUT2
 #undef CH_PUT1
 #undef CH_ADV
 #undef CH_READ
-#undef CH_ADDR
 #undef CH_MID
 #undef CH_G
 }
@@ -2157,7 +2130,7 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
         v.y += lds_tab;  // next-table offsets -> LDS addresses
         tab[i] = v;
     }
-    const ChainWalk cw = {lds_tab | ((32u - CH_ROOT_BITS) << 24), lds_tab, max_len >= 32, lds_stage & ~127u};
+    const ChainWalk cw = {lds_tab | ((32u - CH_ROOT_BITS) << 24), lds_tab, max_len >= 32};
     uint32_t parity = 0;
     for (;;) {
         __syncthreads();  // tables staged (first trip); everybody is done with the ticket word and the stages
@@ -2432,11 +2405,7 @@ void launch_encode(hipStream_t stream, const uint8_t *base, uint64_t lo, uint64_
                    const unsigned long long *tile_off, const uint2 *enc_table, uint32_t max_len, uint32_t *out32, KernelEvents ev) {
     if (max_len > 32)
         ET_LAUNCH_TIMED(k_encode_tiles_long, dim3(tile_grid(k_encode_tiles_long, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
-#ifdef ET_PROBE_K4_BIG_RING  // timing probe: the 8192-word ring (32 KiB: 4 workgroups per CU instead of 8) for every code table
-    else if (false)
-#else
     else if (max_len <= 31)  // a round emits at most 4096 * 31 / 32 + 2 words: fits a 4096-word ring
-#endif
         ET_LAUNCH_TIMED(k_encode_tiles<4096>, dim3(tile_grid(k_encode_tiles<4096>, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);
     else
         ET_LAUNCH_TIMED(k_encode_tiles<8192>, dim3(tile_grid(k_encode_tiles<8192>, n_tiles)), dim3(BLOCK), 0, stream, ev, base, lo, hi, rounds_per_tile, n_tiles, tile_off, enc_table, out32);

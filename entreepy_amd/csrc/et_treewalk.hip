@@ -110,11 +110,7 @@ __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS],
         for (int u = 0; u < TW_LANES; ++u) {
             const int bit = BIT0 + 8 * j;
             const uint32_t f2 = ((W[u][bit >> 5] >> (24 - (bit & 31))) & 0xffu) << 1;
-#ifdef ET_PROBE_D1_PRIVATE_READS  // timing probe (results are wrong): every lane's lookups go to its own bank, in the row it stands in
-            const uint32_t e = *reinterpret_cast<const tw_lds_u16 *>(static_cast<uintptr_t>(tab + R[u] + (((f2 >> 7) & 3u) << 7) + ((threadIdx.x & 31u) << 2) + (f2 & 2u)));
-#else
             const uint32_t e = *reinterpret_cast<const tw_lds_u16 *>(static_cast<uintptr_t>(tab + (R[u] | f2)));
-#endif
             bool on = true;
             if (EDGE) on = on && static_cast<uint32_t>(step0 + j) < limit[u];
             if (SKIP && j < 4) on = on && static_cast<uint32_t>(j) >= skip[u];

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A second build of the library with extra compiler flags, for A/B runs in one tree (ET_LIB_PATH picks it up):
 #   tools/build_variant.sh <name> "<flags>"   ->  variants/libet_<name>.so     (variants/ is git-ignored scratch)
+# The round-3 timing probes (profiles/r03_probes.txt): git apply tools/probe/r03_probes.patch first, then e.g.
+#   tools/build_variant.sh d3s0 "-DET_PROBE_D3_NO_STORES"; on the GPU box: ET_BENCH_NO_VERIFY=1 bash tools/ab_env.sh base "d3s0:ET_LIB_PATH=$PWD/variants/libet_d3s0.so"
 set -e
 cd "$(dirname "$0")/.."
 name=$1; flags=$2
