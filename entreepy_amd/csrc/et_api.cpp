@@ -331,7 +331,6 @@ extern "C" const char *et_version(void) { return "entreepy-hip 0.1.0 (gfx950; .e
 
 extern "C" const char *et_last_error(const et_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
 
-extern "C" size_t et_encode_bound(size_t n) { return (n + 7200 + 15) & ~static_cast<size_t>(15); }
 
 extern "C" int et_ctx_create(int device, et_ctx **out) {
     if (!out) return ET_ERR_ARG;

@@ -91,6 +91,8 @@ private:
 }  // namespace
 
 // (here, with the rest of the plain host code: every host of the C ABI's status codes links this file)
+extern "C" size_t et_encode_bound(size_t n) { return (n + 7200 + 15) & ~static_cast<size_t>(15); }  // encode.zig:253-254
+
 extern "C" const char *et_strerror(int status) {
     switch (status) {
         case ET_OK: return "ok";

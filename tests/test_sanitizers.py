@@ -384,3 +384,122 @@ def test_treewalk_host_part_under_asan_ubsan(tmp_path):
     subprocess.check_call(cmd)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+GROUP_DRIVER = textwrap.dedent(r"""
+    #include "entreepy_hip.h"
+    #include "et_oracle.h"
+    #include <condition_variable>
+    #include <cstdio>
+    #include <cstring>
+    #include <mutex>
+    #include <thread>
+    #include <vector>
+    // The group sequence (et_shard_seq.cpp, the file the product is built from) over the CPU stand-in, rank THREADS of one
+    // process: ragged cuts, dirty buffers, cold decode whole and windowed, a failure injected on one rank -- under ASan + UBSan.
+    static uint64_t rng = 0x243F6A8885A308D3ull;
+    static uint64_t next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; }
+    struct Exchange {
+        std::mutex m; std::condition_variable cv; int world = 1, arrived = 0, gen = 0; std::vector<uint8_t> slots;
+        void meet(std::unique_lock<std::mutex> &lk) { const int g = gen; if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+        static int gather(void *user, const void *send, void *recv, size_t bytes) {
+            auto *x = static_cast<std::pair<Exchange *, int> *>(user); Exchange &e = *x->first;
+            std::unique_lock<std::mutex> lk(e.m);
+            if (e.slots.size() < bytes * e.world) e.slots.resize(bytes * e.world);
+            std::memcpy(e.slots.data() + bytes * x->second, send, bytes);
+            e.meet(lk); std::memcpy(recv, e.slots.data(), bytes * e.world); e.meet(lk);
+            return 0;
+        }
+    };
+    int main() {
+        int bad = 0, relayed = 0, images = 0, decodes = 0;
+        for (int trial = 0; trial < 120; ++trial) {
+            const int world = 1 + next() % 4;
+            const size_t n = trial % 9 == 0 ? 1 + next() % 40 : 1 + next() % 90000;
+            std::vector<uint8_t> text(n);
+            const int mode = trial % 3, k = 2 + next() % 200;
+            for (auto &b : text) b = mode == 0 ? (uint8_t)(next() % k) : mode == 1 ? (uint8_t)(__builtin_ctzll(next() | (1ull << 40))) : (uint8_t)(32 + next() % 64 % (1 + next() % 64));
+            std::vector<size_t> cuts(world + 1, 0); cuts[world] = n;
+            for (int r = 1; r < world; ++r) cuts[r] = next() % (n + 1);
+            std::sort(cuts.begin(), cuts.end());
+            std::vector<uint8_t> want(n + 7200);
+            const int64_t want_len = et_oracle_encode(text.data(), n, want.data(), want.size());
+            if (want_len < 0) { std::printf("oracle encode failed\n"); return 1; }
+            std::vector<uint8_t> image(((size_t)want_len + 3) / 4 * 4, 0xEE);
+            Exchange ex; ex.world = world;
+            std::vector<std::pair<Exchange *, int>> who(world);
+            std::vector<et_group *> grp(world, nullptr);
+            for (int r = 0; r < world; ++r) { who[r] = {&ex, r}; if (et_group_create(nullptr, r, world, Exchange::gather, &who[r], &grp[r]) != ET_OK) return 1; }
+            std::vector<std::vector<uint8_t>> enc(world);
+            for (int r = 0; r < world; ++r) enc[r].assign(et_encode_bound(cuts[r + 1] - cuts[r]) + 64, 0xA5);
+            std::vector<int> rc(world, 0);
+            auto run = [&](auto body) { std::vector<std::thread> th; for (int r = 0; r < world; ++r) th.emplace_back([&, r] { rc[r] = body(r); }); for (auto &t : th) t.join(); };
+            const int victim = (int)(next() % world);
+            if (trial % 4 == 1) {  // one rank without its output buffer: everybody must return that
+                run([&](int r) { et_shard_info i; return et_encode_sharded(grp[r], text.data() + cuts[r], cuts[r + 1] - cuts[r], r == victim ? nullptr : enc[r].data(), enc[r].size(), &i); });
+                for (int r = 0; r < world; ++r) if (rc[r] != ET_ERR_ARG) { ++bad; std::printf("trial %d: rank %d returned %d for rank %d's failure\n", trial, r, rc[r], victim); }
+                ++relayed;
+            }
+            run([&](int r) {
+                et_shard_info i;
+                int c = et_encode_sharded(grp[r], text.data() + cuts[r], cuts[r + 1] - cuts[r], enc[r].data(), enc[r].size(), &i);
+                if (c == ET_OK) c = et_shard_merge_seams(grp[r], enc[r].data());
+                if (c == ET_OK) c = et_shard_place(grp[r], enc[r].data(), image.data(), image.size());
+                return c;
+            });
+            bool all_ok = true, all_cap = true;
+            for (int r = 0; r < world; ++r) { all_ok = all_ok && rc[r] == ET_OK; all_cap = all_cap && rc[r] == ET_ERR_CAP; }
+            if (all_cap) { for (auto g : grp) et_group_destroy(g); continue; }  // (a shard of rare symbols that outgrows et_encode_bound: said by all)
+            if (!all_ok || std::memcmp(image.data(), want.data(), (size_t)want_len)) { ++bad; std::printf("trial %d: image differs (world %d, n %zu)\n", trial, world, n); for (auto g : grp) et_group_destroy(g); continue; }
+            ++images;
+            // cold decode: whole stream on every rank, or each rank's own window
+            const uint8_t *comp = want.data() + 4; const size_t len = (size_t)want_len - 4;
+            std::vector<uint8_t> truth(n + 64); const int64_t truth_len = et_oracle_decode(comp, len, truth.data(), truth.size());
+            et_codebook cb; uint64_t ns = 0; size_t off = 0;
+            if (truth_len < 0 || et_parse_header(comp, len, &cb, &ns, &off) != ET_OK || cb.max_length > 32) { for (auto g : grp) et_group_destroy(g); continue; }
+            std::vector<std::vector<uint8_t>> out(world, std::vector<uint8_t>(n + 64));
+            std::vector<size_t> wrote(world, 0); std::vector<uint64_t> first(world, 0);
+            const bool windowed = next() & 1;
+            // (the stand-in wants 4-byte aligned streams, like the GPU: comp = want + 4 of a vector's data is)
+            std::vector<std::vector<uint32_t>> win(world);
+            run([&](int r) {
+                if (!windowed) return et_decode_sharded(grp[r], comp, len, out[r].data(), out[r].size(), &wrote[r], &first[r]);
+                uint64_t wo = 0, wl = 0, mine = 0;
+                const size_t head_len = len < 8192 ? len : 8192;
+                int c = et_decode_shard_window(comp, head_len, len, r, world, &wo, &wl);
+                if (c != ET_OK) return c;
+                win[r].assign((wl + 3) / 4 + 1, 0);
+                std::memcpy(win[r].data(), comp + wo, wl);
+                c = et_decode_sharded_begin(grp[r], comp, head_len, len, wl ? win[r].data() : nullptr, wo, wl, ~0ull, &mine, &first[r]);
+                if (c == ET_OK) c = et_decode_sharded_write(grp[r], out[r].data(), out[r].size(), &wrote[r]);
+                return c;
+            });
+            std::vector<uint8_t> got;
+            bool ok = true; uint64_t pos = 0;
+            for (int r = 0; r < world; ++r) { ok = ok && rc[r] == ET_OK && (wrote[r] == 0 || first[r] == pos); pos += wrote[r]; got.insert(got.end(), out[r].begin(), out[r].begin() + wrote[r]); }
+            if (!ok || (int64_t)got.size() != truth_len || std::memcmp(got.data(), truth.data(), got.size())) { ++bad; std::printf("trial %d: decode differs (world %d, n %zu, windowed %d)\n", trial, world, n, (int)windowed); }
+            else ++decodes;
+            for (auto g : grp) et_group_destroy(g);
+        }
+        std::printf("%s images %d decodes %d relayed %d\n", bad ? "FAILED" : "ok", images, decodes, relayed);
+        return bad ? 1 : 0;
+    }
+""")
+
+
+@pytest.mark.skipif(subprocess.run(["which", "g++"], capture_output=True).returncode != 0, reason="g++ missing")
+def test_group_sequence_under_asan_ubsan(tmp_path):
+    """csrc/et_shard_seq.cpp -- the group sequence of the product, as it is -- over the CPU stand-in (tests/support/shard_cpu.cpp),
+    rank threads of one process, under AddressSanitizer + UBSan: images equal the oracle's, cold decodes (whole and windowed) return
+    the text, an injected failure comes back from every rank."""
+    src = tmp_path / "driver.cpp"
+    src.write_text("#include <algorithm>\n" + GROUP_DRIVER)
+    exe = tmp_path / "driver"
+    obj = tmp_path / "oracle.o"
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-c", f"{ROOT}/oracle/et_oracle.c", "-o", str(obj)])
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           f"-I{ROOT}/include", f"-I{ROOT}/oracle", f"-I{ROOT}/entreepy_amd/csrc", str(src), f"{ROOT}/entreepy_amd/csrc/et_shard_seq.cpp",
+           f"{ROOT}/tests/support/shard_cpu.cpp", f"{ROOT}/entreepy_amd/csrc/et_codebook.cpp", str(obj), "-o", str(exe)]
+    subprocess.check_call(cmd)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().startswith("ok"), out.stdout[-3000:] + out.stderr[-3000:]
