@@ -2390,11 +2390,8 @@ void launch_header_to_host(hipStream_t stream, const void *d_src, uint32_t n, vo
 void launch_tile_scan(hipStream_t stream, const uint32_t *tile_hist, uint32_t n_tiles, const uint8_t *lengths, const uint32_t *host_src, uint32_t *dev_dst,
                       uint32_t copy_words, unsigned long long *host_taken, unsigned long long taken_epoch, unsigned long long *tile_bits, unsigned long long *group_sum, uint32_t epoch, unsigned long long base_bit,
                       unsigned long long *tile_off, uint32_t *out32, const uint32_t *header_src, uint32_t header_words) {
-#ifndef ET_TILE_BITS_GRID
-#define ET_TILE_BITS_GRID MAX_GRID
-#endif
     uint32_t grid = (n_tiles + 3) / 4;
-    if (grid > ET_TILE_BITS_GRID) grid = ET_TILE_BITS_GRID;
+    if (grid > MAX_GRID) grid = MAX_GRID;  // (one tile per wavefront, 8192 workgroups: no faster, r03)
     CodeLengths cl;
     for (int l = 0; l < 64; ++l) cl.packed[l] = lengths[4 * l] | (lengths[4 * l + 1] << 8) | (lengths[4 * l + 2] << 16) | (static_cast<uint32_t>(lengths[4 * l + 3]) << 24);
     hipLaunchKernelGGL(k_tile_bits, dim3(grid), dim3(BLOCK), 0, stream, tile_hist, n_tiles, cl, tile_bits, host_src, dev_dst, copy_words, host_taken, taken_epoch);
