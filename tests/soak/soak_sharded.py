@@ -128,6 +128,7 @@ def main():
                     head = want[4 : 4 + 8192]
                     off, ln = groups[r].decode_window(head, comp.numel())
                     window = comp[off : off + ln].clone() if ln else None
+                    torch.cuda.synchronize()  # (the clone runs on torch's stream, the group's calls on its context's own)
                     mine, first = groups[r].decode_begin(head, comp.numel(), window, off)
                     m = groups[r].decode_write(outs[r]) if mine else 0
                     assert m == mine
