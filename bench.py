@@ -250,6 +250,9 @@ def main():
     # steps to come back after an idle stretch such as the verification's 0.1 s (the write kernel: 0.59 ms falling to 0.49,
     # rocprofv3 trace).  Both figures are in the line; `value` is the steady state, value_cold the run as the contract
     # words it (same code, same K, only the number of untimed steps before it differs).
+    # (the harness's own comparison kernels are loaded before the pipeline first runs: the verification below then costs a
+    # fraction of a millisecond instead of ~0.1 s of module loading with the GPU idle and its clocks falling)
+    torch.equal(dec[:n], text)
     for _ in range(2):
         step(False, True)
     torch.cuda.synchronize()
