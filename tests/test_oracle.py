@@ -179,3 +179,17 @@ def test_fast_cpu_variant_equals_the_restatement(threads):
         want = O.encode(data)
         assert F.encode(data, threads) == want
         assert F.decode(want[4:], threads) == O.decode(want[4:])
+
+
+def test_fast_cpu_variant_equals_the_restatement_at_64_mib():
+    """The 1 GiB byte-exact GPU test (test_gpu_configs.py) compares with the fast CPU variant; this ties that variant to the
+    restatement at a size where every code path of its chunking is long since in play (64 MiB of the bench's text stream, 8 and
+    3 threads: chunks that do not divide the stream evenly), beside the small cases above."""
+    from oracle import cpu_fast as F
+    from tests import corpus
+
+    data = corpus.text_like(64 << 20, 0x5EED0004)
+    want = O.encode(data)
+    for threads in (8, 3):
+        assert F.encode(data, threads) == want
+    assert F.decode(want[4:], 8) == data.tobytes()
