@@ -131,7 +131,12 @@ def encode_bound(n):
 
 
 class Context:
-    """One et_ctx: a GPU's stream, workspaces and pinned staging."""
+    """One et_ctx: a GPU's stream, workspaces and pinned staging.
+
+    A new context runs on a non-blocking stream of its OWN.  The *_device calls are ordered on that stream only:
+    a torch tensor produced on torch's current stream (a clone, a copy, a kernel) is not waited for.  Call
+    use_torch_stream() to run on torch's current stream instead (sharded.ShardedCodec and the tests' fixture do), or
+    synchronise before handing such tensors in."""
 
     def __init__(self, device=0):
         self._h = ctypes.c_void_p()

@@ -1,5 +1,5 @@
 """GPU: every BASELINE.json config at full size, the sharded path through the C ABI
-(et_sharded.cpp) with several ranks in one process, and the CLI's --gpus.
+(et_shard_seq.cpp + et_shard_hip.cpp) with several ranks in one process, and the CLI's --gpus.
 
 Config 5 (16 GiB uniform random, all 256 byte values) lies outside the reference's lossless domain:
 the reference drops the most frequent symbol (Q1) and its 32-bit length field wraps (Q4), so encode
