@@ -217,7 +217,7 @@ def main():
             te = pipe.encode_timings()
             for k in ("hist", "enc_host", "enc_scan", "enc_body", "enc_total", "exchange"):
                 phases[k] += te[k]
-        state.update(r)
+        state["layout"] = r
         state["decoded"] = m
 
     def barrier():
@@ -264,6 +264,7 @@ def main():
     for _ in range(SETTLE_STEPS):
         step(False, True)
     elapsed = timed_region()
+    m_bytes = state["layout"]["body_bytes"]  # packed body bytes of this rank's shard (worked out here, off the timed path)
     assert not verify or (state["decoded"] == n and torch.equal(dec[:n], text)), "round trip of the last timed step is not the identity"
 
     # N > 1: the bit-offset-adjusted concatenation of the shards into ONE image on rank 0 (seam merge + owned
@@ -327,7 +328,6 @@ def main():
     if rank == 0:
         K = args.steps
         ms = {k: v / K for k, v in phases.items()}
-        m_bytes = state["body_bytes"]          # packed body bytes of this rank's shard
         sync_launches = phases["sync_launches"] / K
         kernels = {
             # name: (ms per launch, algorithmic bytes per launch).  Each of the four kernels carries

@@ -259,9 +259,11 @@ class Context:
         _check(N.lib().et_encode_device(self._h, text.data_ptr(), text.numel(), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
         return n.value
 
-    def decode_device(self, compressed_text, out):
+    def decode_device(self, compressed_text, out, skip=0, length=None):
+        """compressed_text[skip : skip + length] (default: to its end) -> out; the offsets spare the caller a tensor view."""
         n = ctypes.c_size_t(0)
-        _check(N.lib().et_decode_device(self._h, compressed_text.data_ptr(), compressed_text.numel(), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
+        length = compressed_text.numel() - skip if length is None else length
+        _check(N.lib().et_decode_device(self._h, compressed_text.data_ptr() + skip, length, out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
         return n.value
 
     # -- staged calls (sharded encode) ----------------------------------------------

@@ -73,6 +73,22 @@ def cut_blocks(stream_bytes):
     return n_blocks
 
 
+class _SingleLayout(dict):
+    """Layout of a one-GPU encode.  "header_len" / "body_bytes" are worked out when somebody asks (from the call's own code
+    table: 9 bytes + the bit-packed dictionary, encode.zig:259-299) -- not on the path between an encode and the decode behind it."""
+
+    def __init__(self, ctx, **kw):
+        super().__init__(**kw)
+        self._ctx = ctx
+
+    def __missing__(self, key):
+        if key not in ("header_len", "body_bytes"):
+            raise KeyError(key)
+        hdr = len(self._ctx.last_codebook().header(self["n"]))
+        self["header_len"], self["body_bytes"] = hdr, self["et_len"] - hdr
+        return self[key]
+
+
 class ShardedCodec:
     """ctx: this rank's Context; group: the torch.distributed process group (None: one GPU, no group);
     lib_group: a codec.Group to sequence through instead of one made here, or a callable(codec) that makes one (tests:
@@ -118,10 +134,7 @@ class ShardedCodec:
         ctx = self.ctx
         if self.group is None:
             et_len = ctx.encode_device(text, enc)
-            # header length from the call's own code table (9 bytes + the bit-packed dictionary, encode.zig:259-299)
-            hdr = len(ctx.last_codebook().header(n))
-            return {"world": 1, "single": True, "n": n, "et_len": et_len, "header_len": hdr, "body_bytes": et_len - hdr,
-                    "timings": self.single_encode_timings() if timings else None}
+            return _SingleLayout(ctx, world=1, single=True, n=n, et_len=et_len, timings=self.single_encode_timings() if timings else None)
         i = self.lib_group.encode_sharded(text, enc)
         self._host_timings = {"enc_host": i["plan_ms"], "exchange": i["exchange_ms"]}
         return {"world": self.world, "single": False, "n": n, "codebook": self.lib_group.codebook(), "header_len": i["header_len"],
@@ -160,7 +173,7 @@ class ShardedCodec:
         offsets the encode step produced (an in-memory pipeline, not a cold .et read)."""
         ctx = self.ctx
         if layout["single"]:
-            return ctx.decode_device(enc[4 : layout["et_len"]], dec)
+            return ctx.decode_device(enc, dec, 4, layout["et_len"] - 4)  # main.zig:204: text_in[4..]
         start = layout["local_start_bit"]
         byte0 = start // 8
         byte1 = (layout["end_bit"] + 7) // 8

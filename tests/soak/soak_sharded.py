@@ -115,8 +115,11 @@ def main():
             cb, n_symbols, body_off = E.parse_header(want[4:])
             if int(np.asarray(cb.length).max()) > 32:
                 continue
-            truth = O.decode(want[4:])
-            comp = torch.frombuffer(bytearray(want[4:]), dtype=torch.uint8).to(dev)
+            stream = want[4:]
+            if rng.random() < 0.3 and len(stream) > body_off + 20_000:  # a truncated stream: the oracle's decode of what is left
+                stream = stream[: int(rng.integers(body_off + 10_000, len(stream)))]
+            truth = O.decode(stream)
+            comp = torch.frombuffer(bytearray(stream), dtype=torch.uint8).to(dev)
             outs = [torch.zeros(n + 64, dtype=torch.uint8, device=dev) for _ in range(world)]
             torch.cuda.synchronize()
             windowed = rng.random() < 0.5
@@ -125,7 +128,7 @@ def main():
                 if not windowed:
                     m, first = groups[r].decode_sharded(comp, outs[r])
                 else:
-                    head = want[4 : 4 + 8192]
+                    head = stream[:8192]
                     off, ln = groups[r].decode_window(head, comp.numel())
                     window = comp[off : off + ln].clone() if ln else None
                     torch.cuda.synchronize()  # (the clone runs on torch's stream, the group's calls on its context's own)
