@@ -597,7 +597,8 @@ extern "C" int et_decode_sharded(et_group *g, const void *d_compressed, size_t l
     g->err.clear();
     // header and dictionary: parsed on the host, by every rank.  Whatever goes wrong here travels in the first row.
     std::vector<uint8_t> head(len < 8192 ? len : 8192);
-    const uint8_t *h = head.data();
+    static const uint8_t nothing = 0;
+    const uint8_t *h = head.empty() ? &nothing : head.data();  // (an empty stream is a malformed one, not a missing argument)
     int st = ET_OK;
     if (!d_compressed) st = ET_ERR_ARG;
     else if (!head.empty() && (st = g->be->read_head(d_compressed, head.size(), head.data())) != ET_OK) backend_failed(g, st, "reading the header");

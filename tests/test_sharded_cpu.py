@@ -304,6 +304,10 @@ def test_cold_decode_failure_on_one_rank_reaches_all(kind):
     _all_failed_with(res, N.ET_ERR_ARG, naming_rank=0)
     res = _run_ranks(world, lambda r: groups[r].decode_sharded(bad if r == 2 else comp, outs[r]))
     _all_failed_with(res, N.ET_ERR_FORMAT, naming_rank=2)
+    # a stream too short to hold its header, an empty one: malformed, on every rank
+    for short in (comp[:3], comp[:0]):
+        res = _run_ranks(world, lambda r: groups[r].decode_sharded(short.clone() if short.numel() else torch.zeros(0, dtype=torch.uint8), outs[r]))
+        _all_failed_with(res, N.ET_ERR_FORMAT if short.numel() else N.ET_ERR_ARG)
     # and a clean decode on the same groups
     res = _run_ranks(world, lambda r: groups[r].decode_sharded(comp, outs[r]))
     assert all(k == "ok" for k, _ in res), res
