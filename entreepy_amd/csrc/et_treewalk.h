@@ -7,8 +7,9 @@
 // symbols, codes past 20 bits) a third of a percent of the symbols escape, which stalls ~70 % of a
 // wavefront's word iterations.  Here the code table is its binary tree (root = a codeword boundary, one
 // table row per internal node) and every lane consumes exactly one byte per step:
-//     entry[row][byte] (u16) = row after the byte | codewords completed in it << 9
-//                              | bit (0..7) at which the first of them ends << 13
+//     entry[row][byte] (u16) = row after the byte (a tree node: < 256) | codewords completed in it << 8
+//                              | bit (0..7) at which the first of them ends << 12
+// (nibble-aligned: the walk takes the next row with one SDWA shift and adds the count with one v_dot8_u32_u4)
 // No exit test, no escape, no divergence; a 32-bit code is a path through four rows.  What the walk yields
 // per 256-bit subsequence is what the write kernels expect: the bit offset at which its first codeword
 // begins and the number of codewords that begin inside it.
@@ -23,8 +24,8 @@
 
 namespace et {
 
-constexpr uint32_t TW_ROW_BITS = 9, TW_ROW_MASK = (1u << TW_ROW_BITS) - 1u;  // <= 512 rows
-constexpr uint32_t TW_N_SHIFT = 9, TW_OFF_SHIFT = 13;
+constexpr uint32_t TW_ROW_BITS = 8, TW_ROW_MASK = (1u << TW_ROW_BITS) - 1u;  // a byte leads to a tree NODE (< TW_MAX_NODES <= 256); the entry rows are only walked FROM
+constexpr uint32_t TW_N_SHIFT = 8, TW_OFF_SHIFT = 12;
 constexpr uint32_t TW_MAX_NODES = 256;  // internal nodes of a FULL tree over <= 256 leaves (<= 255), + slack
 constexpr uint32_t TW_ENTRY_ROWS = 7;   // rows S_1 .. S_7 behind the nodes': "skip the first b bits of the byte, then from the root"
 constexpr int16_t TW_LEAF0 = -2;        // child value of a leaf: TW_LEAF0 - symbol

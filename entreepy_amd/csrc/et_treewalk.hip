@@ -106,16 +106,25 @@ __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS],
     const uint32_t tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((tw_lds_u8 *)tw_smem));
 #pragma unroll
     for (int j = 0; j < N_STEPS; ++j) {
+        // both lanes' lookups first, then what is done with them: the two reads are in flight together (with one loop over the
+        // lanes the compiler waited for lane 0's entry before it issued lane 1's read -- one LDS round trip at a time per wavefront)
+        uint32_t ee[TW_LANES];
 #pragma unroll
         for (int u = 0; u < TW_LANES; ++u) {
             const int bit = BIT0 + 8 * j;
             const uint32_t f2 = ((W[u][bit >> 5] >> (24 - (bit & 31))) & 0xffu) << 1;
-            const uint32_t e = *reinterpret_cast<const tw_lds_u16 *>(static_cast<uintptr_t>(tab + (R[u] | f2)));
+            ee[u] = *reinterpret_cast<const tw_lds_u16 *>(static_cast<uintptr_t>(tab + R[u] + f2));  // (R = row << 9, f2 < 512: a sum, so that base, row and byte make one v_add3)
+        }
+#pragma unroll
+        for (int u = 0; u < TW_LANES; ++u) {
+            const uint32_t e = ee[u];
             bool on = true;
             if (EDGE) on = on && static_cast<uint32_t>(step0 + j) < limit[u];
             if (SKIP && j < 4) on = on && static_cast<uint32_t>(j) >= skip[u];
-            const uint32_t next = (e << 9) & (TW_ROW_MASK << 9);
+            uint32_t next;  // (e & TW_ROW_MASK) << 9 -- byte 0 of the entry, one SDWA shift (the compiler makes a shift and a mask of it)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(next) : "s"(9u), "v"(e));
             uint32_t n = (e >> TW_N_SHIFT) & 15u;
+            const bool plain = !(EDGE || (SKIP && j < 4)) && !(TRACK && j < 4);  // nobody looks at n: it only joins the count
             if (EDGE || (SKIP && j < 4)) {
                 R[u] = on ? next : R[u];
                 n = on ? n : 0u;
@@ -128,7 +137,8 @@ __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS],
                 t.found[u] = t.found[u] || n > 0;
             }
             // (added here and now: left to itself the compiler keeps every entry of the walk alive and sums them at the end, out of scratch memory)
-            asm volatile("v_add_u32 %0, %0, %1" : "+v"(C[u]) : "v"(n));
+            if (plain) asm volatile("v_dot8_u32_u4 %0, %1, %2, %0" : "+v"(C[u]) : "v"(e), "s"(1u << TW_N_SHIFT));  // C += nibble 2 of the entry: the count, one instruction
+            else asm volatile("v_add_u32 %0, %0, %1" : "+v"(C[u]) : "v"(n));
         }
         // (nothing moves across a step: the compiler otherwise computes every byte offset of the walk up front and spills)
         __builtin_amdgcn_sched_barrier(0);

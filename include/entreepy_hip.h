@@ -157,7 +157,7 @@ int et_selftest_decode_tables(et_ctx *ctx, const et_codebook *cb, int *where);
 /* The synchronisation sweeps of a decode run as a fixed-rate walk over the code TREE when the dictionary is a
  * full binary tree (an encoder's always is): one table row per internal node, one byte of the stream per step
  * (csrc/et_treewalk.h).  et_treewalk_table: that table as the host fills it -- (*n_int + 7) x 256 entries of
- * next row | codewords completed in the byte << 9 | bit at which the first of them ends << 13 -- or
+ * next row | codewords completed in the byte << 8 | bit at which the first of them ends << 12 -- or
  * ET_ERR_UNSUPPORTED when the walk does not apply (table may be NULL to ask just that).
  * et_selftest_treewalk_table: build it on the device (what a decode does) and compare it with the host fill;
  * *first_diff = 1 + the first differing entry. */

@@ -239,7 +239,7 @@ def test_prefix_collision_check_follows_the_reference_loop():
 
 
 def _brute_treewalk_table(data, length):
-    """(row, byte) -> next row | completions << 9 | bit of the first << 13, from the codes alone: rows are the
+    """(row, byte) -> next row | completions << 8 | bit of the first << 12, from the codes alone: rows are the
     proper prefixes of the codes, numbered in the order the library meets them (symbols ascending, bits from
     the first), then 7 entry rows "skip b bits, then from the root"."""
     rows = {(): 0}
@@ -265,7 +265,7 @@ def _brute_treewalk_table(data, length):
                         first = i
                     n += 1
                     cur = ()
-            table[r * 256 + f] = rows[cur] | (n << 9) | (first << 13)
+            table[r * 256 + f] = rows[cur] | (n << 8) | (first << 12)
     return n_int, table
 
 
