@@ -35,16 +35,17 @@ __device__ __forceinline__ uint32_t tw_wave_inclusive_scan(uint32_t x) {
     return x;
 }
 
-// Word `idx` (may be negative: before `words`) of the stream in host order, zero outside it.  front_ok: the four words
-// in front of `words` are stream bytes too (a range of a stream that began earlier).
+// Word `idx` (may be negative: before `words`) of the stream AS IT LIES IN MEMORY (stream byte k of the word is its byte k: the
+// walk picks bytes by SDWA selects, so nothing is swapped), zero outside the stream.  front_ok: the four words in front of `words`
+// are stream bytes too (a range of a stream that began earlier).
 __device__ __attribute__((noinline)) uint32_t tw_load_guarded(const uint32_t *__restrict__ words, long long idx, uint64_t n_bytes, bool front_ok) {
-    if (idx < 0) return front_ok && idx >= -4 ? __builtin_bswap32(words[idx]) : 0u;
+    if (idx < 0) return front_ok && idx >= -4 ? words[idx] : 0u;
     const uint64_t b0 = static_cast<uint64_t>(idx) * 4;
-    if (b0 + 4 <= n_bytes) return __builtin_bswap32(words[idx]);
+    if (b0 + 4 <= n_bytes) return words[idx];
     uint32_t v = 0;
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(words);
     for (int k = 0; k < 4; ++k)
-        if (b0 + k < n_bytes) v |= static_cast<uint32_t>(bytes[b0 + k]) << (24 - 8 * k);
+        if (b0 + k < n_bytes) v |= static_cast<uint32_t>(bytes[b0 + k]) << (8 * k);
     return v;
 }
 
@@ -100,7 +101,7 @@ struct TwTrack {  // where the subsequence's first codeword begins: the bit afte
 // EDGE: only the steps below `limit` count (the stream ends inside the lane's bytes); SKIP: steps below
 // `skip` do not count either (a walk that begins at a bit offset); TRACK: the first four steps also look for
 // the first completion.
-template <int BIT0, int N_STEPS, bool EDGE, bool SKIP, bool TRACK>
+template <int BIT0, int N_STEPS, bool EDGE, bool SKIP, bool TRACK, bool COUNT = true>
 __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS], uint32_t (&R)[TW_LANES], uint32_t (&C)[TW_LANES],
                                         const uint32_t (&skip)[TW_LANES], const uint32_t (&limit)[TW_LANES], int step0, TwTrack &t) {
     const uint32_t tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((tw_lds_u8 *)tw_smem));
@@ -112,7 +113,7 @@ __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS],
 #pragma unroll
         for (int u = 0; u < TW_LANES; ++u) {
             const int bit = BIT0 + 8 * j;
-            const uint32_t f2 = ((W[u][bit >> 5] >> (24 - (bit & 31))) & 0xffu) << 1;
+            const uint32_t f2 = ((W[u][bit >> 5] >> (bit & 31)) & 0xffu) << 1;  // stream byte (bit / 8) % 4 of the word = its byte of that index, as loaded
             ee[u] = *reinterpret_cast<const tw_lds_u16 *>(static_cast<uintptr_t>(tab + R[u] + f2));  // (R = row << 9, f2 < 512: a sum, so that base, row and byte make one v_add3)
         }
 #pragma unroll
@@ -137,7 +138,8 @@ __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS],
                 t.found[u] = t.found[u] || n > 0;
             }
             // (added here and now: left to itself the compiler keeps every entry of the walk alive and sums them at the end, out of scratch memory)
-            if (plain) asm volatile("v_dot8_u32_u4 %0, %1, %2, %0" : "+v"(C[u]) : "v"(e), "s"(1u << TW_N_SHIFT));  // C += nibble 2 of the entry: the count, one instruction
+            if (!COUNT) {  // (a run-in, a look for the first completion: nobody wants the count)
+            } else if (plain) asm volatile("v_dot8_u32_u4 %0, %1, %2, %0" : "+v"(C[u]) : "v"(e), "s"(1u << TW_N_SHIFT));  // C += nibble 2 of the entry: the count, one instruction
             else asm volatile("v_add_u32 %0, %0, %1" : "+v"(C[u]) : "v"(n));
         }
         // (nothing moves across a step: the compiler otherwise computes every byte offset of the walk up front and spills)
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             const long long w0 = static_cast<long long>(q[u]) * 16 - 4;
             if (!edge) {
 #pragma unroll
-                for (int j = 0; j < TW_WORDS; ++j) W[u][j] = __builtin_bswap32(words[w0 + j]);
+                for (int j = 0; j < TW_WORDS; ++j) W[u][j] = words[w0 + j];  // (as they lie in memory: no byte swap, see tw_walk)
             } else {
 #pragma unroll
                 for (int j = 0; j < TW_WORDS; ++j) W[u][j] = tw_load_guarded(words, w0 + j, n_bytes, (mode & TW_FRONT_OK) != 0);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
         const uint32_t no_limit[TW_LANES] = {0xffffffffu, 0xffffffffu};
         {
             TwTrack none = {};
-            tw_walk<0, 16, false, false, false>(W, R0, C0, skip, no_limit, 0, none);
+            tw_walk<0, 16, false, false, false, false>(W, R0, C0, skip, no_limit, 0, none);
         }
         // The block's first lane may KNOW where it begins: the stream's first lane (the root at bit first_bit),
         // or, in a repair sweep, the node the block before ends in.
@@ -354,8 +356,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
                 ta.found[u] = start[u] == 0;  // (also the lane with a known bit offset: it begins there)
                 ta.start[u] = (u == 0 && known_bit) ? first_bit : 0u;
             }
-            if (edge) tw_walk<128, 4, true, false, true>(W, Ra, Ca, skip, limit, 0, ta);
-            else tw_walk<128, 4, false, false, true>(W, Ra, Ca, skip, limit, 0, ta);
+            if (edge) tw_walk<128, 4, true, false, true, false>(W, Ra, Ca, skip, limit, 0, ta);
+            else tw_walk<128, 4, false, false, true, false>(W, Ra, Ca, skip, limit, 0, ta);
             TwTrack tb;
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) {
@@ -365,8 +367,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
                 tb.found[u] = r[u].s_mid == 0;
                 tb.start[u] = 0;
             }
-            if (edge) tw_walk<384, 4, true, false, true>(W, Ra, Ca, skip, limit, 32, tb);
-            else tw_walk<384, 4, false, false, true>(W, Ra, Ca, skip, limit, 32, tb);
+            if (edge) tw_walk<384, 4, true, false, true, false>(W, Ra, Ca, skip, limit, 32, tb);
+            else tw_walk<384, 4, false, false, true, false>(W, Ra, Ca, skip, limit, 32, tb);
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) {
                 st2[u] = tb.found[u] ? tb.start[u] : 0u;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
                 tx.found[u] = r[u].s_out == 0;
                 tx.start[u] = 0;
             }
-            tw_walk<640, 4, false, false, true>(W, Rx, Cx, skip, no_limit, 0, tx);
+            tw_walk<640, 4, false, false, true, false>(W, Rx, Cx, skip, no_limit, 0, tx);
             if (lane_id == 63) *exit_bits = tx.found[1] ? tx.start[1] : 0u;
         }
         uint32_t sum = 0;
