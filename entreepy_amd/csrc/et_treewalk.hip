@@ -88,7 +88,12 @@ __global__ __launch_bounds__(1024) void k_tw_build(const TwUpload *__restrict__ 
 }
 
 // ---- the walk -------------------------------------------------------------------------------------
-constexpr int TW_WORDS = 21;  // W[j] = stream word 16 * lane - 4 + j: 4 run-in words, 16 own, 1 beyond (a block's tail at the stream's end)
+#ifndef ET_TW_RUN_WORDS
+#define ET_TW_RUN_WORDS 4
+#endif
+constexpr int TW_RUN = ET_TW_RUN_WORDS;       // words a lane runs in over before its own
+constexpr int TW_WORDS = TW_RUN + 17;         // W[j] = stream word 16 * lane - TW_RUN + j: the run-in words, 16 own, 1 beyond (a block's tail at the stream's end)
+constexpr int TW_OWN = 32 * TW_RUN;           // bit of W at which the lane's own 512 begin
 constexpr int TW_LANES = 2;   // 512-bit lanes walked by one thread
 constexpr uint32_t TW_PUB_POLLS = 256;  // looks at the word the block before publishes (a short sleep in between: ~100 us in all) before a block gives up on it
 
@@ -153,21 +158,40 @@ __device__ __forceinline__ void tw_walk(const uint32_t (&W)[TW_LANES][TW_WORDS],
     }
 }
 
-struct TwLane {
-    uint32_t s_mid, s_out;  // rows after 256 bits, after 512
-    uint32_t c1, c2;        // codewords completed in the first / second 256 bits
+struct TwLane {  // (two registers per lane, not four: the sweep lives on its wavefronts per SIMD)
+    uint32_t s;  // rows (tree nodes, < 256) after 256 bits | after 512 << 16
+    uint32_t c;  // codewords completed in the first 256 bits (<= 256) | in the second << 16
+    __device__ __forceinline__ uint32_t s_mid() const { return s & 0xffffu; }
+    __device__ __forceinline__ uint32_t s_out() const { return s >> 16; }
+    __device__ __forceinline__ uint32_t c1() const { return c & 0xffffu; }
+    __device__ __forceinline__ uint32_t c2() const { return c >> 16; }
+    __device__ __forceinline__ void first_half(uint32_t count, uint32_t row) {
+        c = (c & 0xffff0000u) | count;
+        s = (s & 0xffff0000u) | row;
+    }
+    __device__ __forceinline__ void second_half(uint32_t count, uint32_t row) {
+        c = (c & 0xffffu) | (count << 16);
+        s = (s & 0xffffu) | (row << 16);
+    }
 };
 
-// Both lanes of a thread from row offsets R0.  `take[u]`: lane u's results are wanted; REWALK: a lane that
-// stands after 256 bits where its old walk stood keeps the rest.
+// Both lanes of a thread from row offsets R0.  `take[u]`: lane u's results are wanted; REWALK: a lane that stands where its
+// old walk stood keeps the rest -- after TW_CK steps (ck[u] = the old walk's row there | the codewords it had completed by
+// then: a row offset's low 9 bits are free), which is where a walk from the wrong node has all but always met the right one (a
+// re-walk is 8 steps instead of 32: they were a quarter of the sweep), and again after 256 bits.
+#ifndef ET_TW_CK_STEPS
+#define ET_TW_CK_STEPS 8
+#endif
+constexpr int TW_CK = ET_TW_CK_STEPS;  // 4 <= TW_CK < 32 (the steps that may skip lie in front of it; a count of <= 8 * TW_CK fits 9 bits)
+static_assert(TW_CK >= 4 && TW_CK < 32 && 8 * TW_CK < 512, "checkpoint step");
 template <bool EDGE, bool REWALK>
 __device__ __forceinline__ void tw_lanes(uint32_t (&W)[TW_LANES][TW_WORDS], const uint32_t (&R0)[TW_LANES], const uint32_t (&skip)[TW_LANES],
-                                         const uint32_t (&limit)[TW_LANES], const bool (&take)[TW_LANES], TwLane (&r)[TW_LANES]) {
+                                         const uint32_t (&limit)[TW_LANES], const bool (&take)[TW_LANES], TwLane (&r)[TW_LANES], uint32_t (&ck)[TW_LANES]) {
     // (the words are "new" to every walk: the compiler otherwise keeps the first walk's byte offsets for the re-walk, in scratch memory)
 #pragma unroll
     for (int u = 0; u < TW_LANES; ++u)
 #pragma unroll
-        for (int j = 4; j < TW_WORDS; ++j) asm volatile("" : "+v"(W[u][j]));
+        for (int j = TW_RUN; j < TW_WORDS; ++j) asm volatile("" : "+v"(W[u][j]));
     uint32_t R[TW_LANES], C[TW_LANES];
     bool redo[TW_LANES];
     bool any_redo = false;
@@ -177,30 +201,50 @@ __device__ __forceinline__ void tw_lanes(uint32_t (&W)[TW_LANES][TW_WORDS], cons
         R[u] = R0[u];
         C[u] = 0;
     }
-    tw_walk<128, 32, EDGE, true, false>(W, R, C, skip, limit, 0, t);
+    tw_walk<TW_OWN, TW_CK, EDGE, true, false>(W, R, C, skip, limit, 0, t);
+    {
+        bool off = false;
+#pragma unroll
+        for (int u = 0; u < TW_LANES; ++u) {
+            const uint32_t here = R[u] | C[u];
+            if (REWALK) off = off || (take[u] && ((here ^ ck[u]) >> 9) != 0);
+            if (REWALK && take[u]) r[u].c += C[u] - (ck[u] & 511u);  // (right if the wavefront stops here; recounted in full if it does not)
+            if (take[u]) ck[u] = here;
+        }
+        if (REWALK && !__any(off)) return;
+    }
+    tw_walk<TW_OWN + 8 * TW_CK, 32 - TW_CK, EDGE, false, false>(W, R, C, skip, limit, TW_CK, t);
 #pragma unroll
     for (int u = 0; u < TW_LANES; ++u) {
         if (EDGE && limit[u] < 32) R[u] = 0;  // the stream ended: nothing is pending
         const uint32_t mid = R[u] >> 9;
-        redo[u] = take[u] && !(REWALK && mid == r[u].s_mid);
-        if (take[u]) {
-            r[u].c1 = C[u];
-            r[u].s_mid = mid;
-        }
+        redo[u] = take[u] && !(REWALK && mid == r[u].s_mid());
+        if (take[u]) r[u].first_half(C[u], mid);
         C[u] = 0;
         any_redo = any_redo || redo[u];
     }
     if (__any(any_redo)) {
-        tw_walk<384, 32, EDGE, false, false>(W, R, C, skip, limit, 32, t);
+        tw_walk<TW_OWN + 256, 32, EDGE, false, false>(W, R, C, skip, limit, 32, t);
 #pragma unroll
         for (int u = 0; u < TW_LANES; ++u) {
             if (EDGE && limit[u] < 64) R[u] = 0;
-            if (redo[u]) {
-                r[u].c2 = C[u];
-                r[u].s_out = R[u] >> 9;
-            }
+            if (redo[u]) r[u].second_half(C[u], R[u] >> 9);
         }
     }
+}
+
+// What the block before block b published -- bit 31 | the node it ends in -- or 0 when that is `guess`, the node b's first lane
+// started from (0 also when nothing shows up within TW_PUB_POLLS looks).  Wavefront-uniform.
+__device__ __forceinline__ uint32_t tw_seen_before(const uint32_t *__restrict__ blk_pub, uint32_t b, uint32_t guess, uint32_t lane_id) {
+    uint32_t seen = 0;
+    if (lane_id == 0) {
+        for (uint32_t poll = 0; poll < TW_PUB_POLLS && !(seen & 0x80000000u); ++poll) {
+            seen = __hip_atomic_load(blk_pub + (b - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(seen & 0x80000000u)) __builtin_amdgcn_s_sleep(8);
+        }
+        if (!(seen & 0x80000000u) || (seen & 0x7fffffffu) == guess) seen = 0;
+    }
+    return __builtin_amdgcn_readfirstlane(seen);
 }
 
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_tw_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
@@ -227,7 +271,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
     // by ticket, so that a wavefront with a block to do twice takes one fewer, costs 77 K atomics on one address: 0.98 ms.
     // (A block whose end moves in its second attempt -- it did not re-synchronise within 8 KiB -- leaves a stale word
     // behind; the verification scan sees the mismatch and the host sweeps again.)
-    uint32_t it = blockIdx.x * waves_per_group + (tid >> 6), again_b = 0, again_row = 0xffffffffu;
+    // A block is held against the block before it ONE TRIP LATE (`pend_b`): looked at right behind its own walk, the word of
+    // the block before is often not there yet (that block had a seam to settle, a slower lookup), the wavefront sleeps, starts
+    // its next block late, publishes late, and the lateness travels from neighbour to neighbour -- the sweep ran at the pace
+    // of the slowest of any two neighbours, trip after trip (0.227 ms; without the look 0.18).  A trip later the word has been
+    // there for ~20 us.  What a late look costs: a block that turns out to begin elsewhere has already stored its results;
+    // its second attempt stores them again (same wavefront, same addresses: in order).
+    uint32_t it = blockIdx.x * waves_per_group + (tid >> 6), again_b = 0, again_row = 0xffffffffu, pend_b = 0xffffffffu, pend_start = 0;
     for (;;) {
         uint32_t b, forced = 0xffffffffu;
         if (again_row != 0xffffffffu) {
@@ -237,13 +287,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
         } else if (it < n_todo) {
             b = worklist ? worklist[it] : it;
             it += gridDim.x * waves_per_group;
+        } else if (pend_b != 0xffffffffu) {  // the wavefront's last block has not been looked at yet
+            const uint32_t seen = tw_seen_before(blk_pub, pend_b, pend_start, lane_id);
+            again_b = pend_b;
+            pend_b = 0xffffffffu;
+            if (seen & 0x80000000u) again_row = seen & 0x7fffffffu;
+            continue;
         } else {
             break;
         }
         {
         // wavefront-uniform: every word of the block, its run-in and the word after it is a whole word of the stream
-        const long long bw0 = static_cast<long long>(b) * 2048 - 4;
-        const bool edge = bw0 < 0 || static_cast<uint64_t>(bw0 + 2048 + 4 + 1) > n_words_full;
+        const long long bw0 = static_cast<long long>(b) * 2048 - TW_RUN;
+        const bool edge = bw0 < 0 || static_cast<uint64_t>(bw0 + 2048 + TW_RUN + 1) > n_words_full;
         uint32_t W[TW_LANES][TW_WORDS], limit[TW_LANES];
         uint64_t q[TW_LANES];
         bool live[TW_LANES];
@@ -252,7 +308,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             q[u] = static_cast<uint64_t>(b) * 128 + u * 64 + lane_id;  // 512-bit lane = subsequences 2q, 2q + 1
             live[u] = q[u] < n_lanes;
             limit[u] = 0xffffffffu;
-            const long long w0 = static_cast<long long>(q[u]) * 16 - 4;
+            const long long w0 = static_cast<long long>(q[u]) * 16 - TW_RUN;
             if (!edge) {
 #pragma unroll
                 for (int j = 0; j < TW_WORDS; ++j) W[u][j] = words[w0 + j];  // (as they lie in memory: no byte swap, see tw_walk)
@@ -269,7 +325,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
         const uint32_t no_limit[TW_LANES] = {0xffffffffu, 0xffffffffu};
         {
             TwTrack none = {};
-            tw_walk<0, 16, false, false, false, false>(W, R0, C0, skip, no_limit, 0, none);
+            tw_walk<0, 4 * TW_RUN, false, false, false, false>(W, R0, C0, skip, no_limit, 0, none);
         }
         // The block's first lane may KNOW where it begins: the stream's first lane (the root at bit first_bit),
         // or, in a repair sweep, the node the block before ends in.
@@ -293,15 +349,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             start[u] = (u == 0 && known_bit) ? 0u : R0[u] >> 9;
             take[u] = true;
         }
-        if (edge) tw_lanes<true, false>(W, R0, skip, limit, take, r);
-        else tw_lanes<false, false>(W, R0, skip, limit, take, r);
+        uint32_t ck[TW_LANES] = {};
+        if (edge) tw_lanes<true, false>(W, R0, skip, limit, take, r, ck);
+        else tw_lanes<false, false>(W, R0, skip, limit, take, r, ck);
         skip[0] = 0;
         bool gave_up = false;
         for (uint32_t trip = 1;; ++trip) {
             // lane li's start must be lane li - 1's exit (li = u * 64 + lane); the block's first lane keeps its own
             bool need[TW_LANES], any_need = false;
             uint32_t cand[TW_LANES];
-            const uint32_t up0 = __shfl_up(r[0].s_out, 1), up1 = __shfl_up(r[1].s_out, 1), last0 = __shfl(r[0].s_out, 63);
+            const uint32_t up0 = __shfl_up(r[0].s_out(), 1), up1 = __shfl_up(r[1].s_out(), 1), last0 = __shfl(r[0].s_out(), 63);
             cand[0] = lane_id ? up0 : start[0];
             cand[1] = lane_id ? up1 : last0;
 #pragma unroll
@@ -317,29 +374,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             uint32_t Rn[TW_LANES];
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) Rn[u] = need[u] ? cand[u] << 9 : 0u;
-            if (edge) tw_lanes<true, true>(W, Rn, skip, limit, need, r);
-            else tw_lanes<false, true>(W, Rn, skip, limit, need, r);
+            if (edge) {
+                // (the limits are "new" to every trip: left loop-invariant, the edge walk's 128 step-limit compares are hoisted in
+                // front of the trip loop, where EVERY block pays for them -- 337 of a block's ~1360 VALU instructions)
+                asm volatile("" : "+v"(limit[0]), "+v"(limit[1]));
+                tw_lanes<true, true>(W, Rn, skip, limit, need, r, ck);
+            } else {
+                tw_lanes<false, true>(W, Rn, skip, limit, need, r, ck);
+            }
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) start[u] = need[u] ? cand[u] : start[u];
         }
-        if (blk_pub && !worklist && b != 0 && forced == 0xffffffffu) {
-            if (lane_id == 63) __hip_atomic_store(blk_pub + b, 0x80000000u | r[1].s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t seen = 0;
-            if (lane_id == 0) {
-                for (uint32_t poll = 0; poll < TW_PUB_POLLS && !(seen & 0x80000000u); ++poll) {
-                    seen = __hip_atomic_load(blk_pub + (b - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(seen & 0x80000000u)) __builtin_amdgcn_s_sleep(8);
+        if (blk_pub && !worklist && forced == 0xffffffffu) {
+            if (lane_id == 63) __hip_atomic_store(blk_pub + b, 0x80000000u | r[1].s_out(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pend_b != 0xffffffffu) {  // the block of the trip before: does it begin where the block before IT ends?
+                const uint32_t seen = tw_seen_before(blk_pub, pend_b, pend_start, lane_id);
+                if (seen & 0x80000000u) {  // (never seen: the block keeps its guess, the verification decides)
+                    again_b = pend_b;
+                    again_row = seen & 0x7fffffffu;
                 }
-                if (!gave_up && (seen & 0x7fffffffu) == start[0]) seen = 0;  // as guessed
             }
-            seen = __builtin_amdgcn_readfirstlane(seen);
-            if (seen & 0x80000000u) {  // (never seen: the block keeps its guess, the verification decides)
-                again_b = b;
-                again_row = seen & 0x7fffffffu;
-                continue;
-            }
-        } else if (blk_pub && !worklist && b == 0 && lane_id == 63) {
-            __hip_atomic_store(blk_pub + b, 0x80000000u | r[1].s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (a block that gave up is done again whatever the block before it says: no row is 0x7fffffff)
+            pend_b = b ? __builtin_amdgcn_readfirstlane(b) : 0xffffffffu;
+            pend_start = __builtin_amdgcn_readfirstlane(gave_up ? 0x7fffffffu : start[0]);
         }
         // Where each subsequence's first codeword begins: one past the first completion seen from the node at
         // its first bit -- four more steps per half, once the nodes are settled (tracked inside the walks it
@@ -356,19 +413,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
                 ta.found[u] = start[u] == 0;  // (also the lane with a known bit offset: it begins there)
                 ta.start[u] = (u == 0 && known_bit) ? first_bit : 0u;
             }
-            if (edge) tw_walk<128, 4, true, false, true, false>(W, Ra, Ca, skip, limit, 0, ta);
-            else tw_walk<128, 4, false, false, true, false>(W, Ra, Ca, skip, limit, 0, ta);
+            if (edge) tw_walk<TW_OWN, 4, true, false, true, false>(W, Ra, Ca, skip, limit, 0, ta);
+            else tw_walk<TW_OWN, 4, false, false, true, false>(W, Ra, Ca, skip, limit, 0, ta);
             TwTrack tb;
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) {
                 st1[u] = ta.found[u] ? ta.start[u] : 0u;
                 f1[u] = ta.found[u];
-                Ra[u] = r[u].s_mid << 9;
-                tb.found[u] = r[u].s_mid == 0;
+                Ra[u] = r[u].s_mid() << 9;
+                tb.found[u] = r[u].s_mid() == 0;
                 tb.start[u] = 0;
             }
-            if (edge) tw_walk<384, 4, true, false, true, false>(W, Ra, Ca, skip, limit, 32, tb);
-            else tw_walk<384, 4, false, false, true, false>(W, Ra, Ca, skip, limit, 32, tb);
+            if (edge) tw_walk<TW_OWN + 256, 4, true, false, true, false>(W, Ra, Ca, skip, limit, 32, tb);
+            else tw_walk<TW_OWN + 256, 4, false, false, true, false>(W, Ra, Ca, skip, limit, 32, tb);
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) {
                 st2[u] = tb.found[u] ? tb.start[u] : 0u;
@@ -383,12 +440,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             uint32_t Rt[TW_LANES], Ct[TW_LANES] = {}, lim_t[TW_LANES];
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) {
-                Rt[u] = r[u].s_out << 9;
+                Rt[u] = r[u].s_out() << 9;
                 const uint64_t after = (q[u] + 1) * 64;
                 lim_t[u] = static_cast<uint32_t>(n_bytes > after ? (n_bytes - after < 4 ? n_bytes - after : 4) : 0);
             }
             TwTrack tt = {};
-            tw_walk<640, 4, true, false, false>(W, Rt, Ct, skip, lim_t, 0, tt);
+            tw_walk<TW_OWN + 512, 4, true, false, false>(W, Rt, Ct, skip, lim_t, 0, tt);
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) out_ok[u] = Ct[u] > 0;
         }
@@ -399,33 +456,37 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
             TwTrack tx;
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) {
-                Rx[u] = r[u].s_out << 9;
-                tx.found[u] = r[u].s_out == 0;
+                Rx[u] = r[u].s_out() << 9;
+                tx.found[u] = r[u].s_out() == 0;
                 tx.start[u] = 0;
             }
-            tw_walk<640, 4, false, false, true, false>(W, Rx, Cx, skip, no_limit, 0, tx);
+            tw_walk<TW_OWN + 512, 4, false, false, true, false>(W, Rx, Cx, skip, no_limit, 0, tx);
             if (lane_id == 63) *exit_bits = tx.found[1] ? tx.start[1] : 0u;
         }
+        // (the lanes' numbers worked out again rather than kept in four registers across the walks: the kernel is at its register limit)
+        uint32_t b_again = b;
+        asm volatile("" : "+v"(b_again));
         uint32_t sum = 0;
         const uint32_t next_st0 = __shfl_down(st1[0], 1), next_st1 = __shfl_down(st1[1], 1), first1 = __shfl(st1[1], 0);
 #pragma unroll
         for (int u = 0; u < TW_LANES; ++u) {
-            const uint32_t begun1 = r[u].c1 - ((start[u] != 0 && f1[u]) ? 1u : 0u) + ((r[u].s_mid != 0 && f2[u]) ? 1u : 0u);
-            const uint32_t begun2 = r[u].c2 - ((r[u].s_mid != 0 && f2[u]) ? 1u : 0u) + ((r[u].s_out != 0 && out_ok[u]) ? 1u : 0u);
+            const uint32_t begun1 = r[u].c1() - ((start[u] != 0 && f1[u]) ? 1u : 0u) + ((r[u].s_mid() != 0 && f2[u]) ? 1u : 0u);
+            const uint32_t begun2 = r[u].c2() - ((r[u].s_mid() != 0 && f2[u]) ? 1u : 0u) + ((r[u].s_out() != 0 && out_ok[u]) ? 1u : 0u);
             // the start of the subsequence after this lane: the next lane's (the block's last lane: not known here, 0)
             const uint32_t after = u == 0 ? (lane_id == 63 ? first1 : next_st0) : (lane_id == 63 ? 0u : next_st1);
+            const uint64_t qu = static_cast<uint64_t>(b_again) * 128 + u * 64 + lane_id;
             if (live[u]) {
                 uint32_t first = st1[u];
                 if (gave_up && u == 0 && lane_id == 0) first = 0xffu;  // the marker the write kernels' launch rule knows
-                sub_state[2 * q[u]] = first | (st2[u] << 8) | (begun1 << 16);
-                if (2 * q[u] + 1 < n_subs) sub_state[2 * q[u] + 1] = st2[u] | (after << 8) | (begun2 << 16);
+                sub_state[2 * qu] = first | (st2[u] << 8) | (begun1 << 16);
+                if (2 * qu + 1 < n_subs) sub_state[2 * qu + 1] = st2[u] | (after << 8) | (begun2 << 16);
                 sum += begun1 + begun2;
             }
         }
         sum = tw_wave_inclusive_scan(sum);
         if (lane_id == 63) {
             blk_count[b] = sum;
-            blk_exit[b] = r[1].s_out;  // (lanes past the stream's end stand at the root)
+            blk_exit[b] = r[1].s_out();  // (lanes past the stream's end stand at the root)
         }
         if (lane_id == 0) {
             blk_start[b] = gave_up ? 0xffffffffu : start[0];
