@@ -60,17 +60,19 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t x) {
 // `scratch` is 4 LDS words.  Contains ONE barrier; the caller must separate two
 // calls that reuse `scratch` by another barrier.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *scratch, uint32_t *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (scalar: what lies before a wavefront is added up on the scalar unit)
     const uint32_t inc = wave_inclusive_scan(x);
     if (lane == 63) scratch[wave] = inc;
     __syncthreads();
-    const uint32_t w0 = scratch[0], w1 = scratch[1], w2 = scratch[2], w3 = scratch[3];
+    const uint32_t w0 = __builtin_amdgcn_readfirstlane(scratch[0]), w1 = __builtin_amdgcn_readfirstlane(scratch[1]),
+                   w2 = __builtin_amdgcn_readfirstlane(scratch[2]), w3 = __builtin_amdgcn_readfirstlane(scratch[3]);
     uint32_t before = 0;
     if (wave > 0) before += w0;
     if (wave > 1) before += w1;
     if (wave > 2) before += w2;
     *total = w0 + w1 + w2 + w3;
-    return before + inc - x;
+    return before + (inc - x);
 }
 
 // --------------------------------------------------------------------------------
@@ -493,24 +495,23 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
 #define ET_ENTRY(k_) tab[(cur.w[(k_) >> 2] >> (8 * ((k_) & 3))) & 0xffu]
             uint32_t qcode[4], qlen[4];
             uint32_t tot = 0;
-            bool wide4 = false, wide2 = false;  // some quad / some pair of this lane exceeds 32 bits
+            bool wide4 = false;  // some quad of this lane exceeds 32 bits (a pair that does makes its quad do so too: pairs are looked at only then)
             if (cur.valid == 0xffffu) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint2 e0 = ET_ENTRY(4 * q), e1 = ET_ENTRY(4 * q + 1), e2 = ET_ENTRY(4 * q + 2), e3 = ET_ENTRY(4 * q + 3);
                     const uint32_t l01 = e0.y + e1.y, l23 = e2.y + e3.y;
-                    const uint32_t c01 = e0.x | (e1.x >> (e0.y & 31u)), c23 = e2.x | (e3.x >> (e2.y & 31u));  // a 32-bit first code with a non-empty second is `wide2`
+                    const uint32_t c01 = e0.x | (e1.x >> (e0.y & 31u)), c23 = e2.x | (e3.x >> (e2.y & 31u));  // (garbage for a 32-bit first code with a non-empty second: that quad is wide)
                     qlen[q] = l01 + l23;
                     qcode[q] = c01 | (c23 >> (l01 & 31u));
-                    wide2 |= l01 > 32 || l23 > 32;
-                    wide4 |= qlen[q] > 32;
-                    tot += qlen[q];
                 }
-                wide4 |= wide2;
+                // one maximum and one compare for the four quads, two three-operand adds for their total
+                wide4 = max(max(qlen[0], qlen[1]), max(qlen[2], qlen[3])) > 32u;
+                tot = (qlen[0] + qlen[1] + qlen[2]) + qlen[3];
             } else {  // bytes outside the stream carry no bits
-                wide4 = wide2 = true;
+                wide4 = true;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) qcode[q] = qlen[q] = 0;
+                for (int q = 0; q < 4; ++q) qcode[q] = 0, qlen[q] = 64;  // (every quad "wide": the single-symbol path below)
                 for (int k = 0; k < 16; ++k)
                     if ((cur.valid >> k) & 1u) tot += ET_ENTRY(k).y;
             }
@@ -531,32 +532,46 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
         const uint32_t nf_ = fill + (len_);                                                       \
         if (nf_ >= 32) {                                                                          \
             atomicOr(reinterpret_cast<uint32_t *>(ring_bytes + wbyte), part);                     \
-            part = ((piece_) << 1) << (31 - fill); /* what did not fit; 0 when fill == 0 */       \
+            part = __builtin_amdgcn_alignbit((piece_), 0u, fill); /* what did not fit: piece << (32 - fill), 0 when fill == 0 -- one instruction */ \
             wbyte = (wbyte + 4) & (RING_WORDS * 4 - 1);                                           \
         }                                                                                         \
         fill = nf_ & 31;                                                                          \
     } while (0)
-            if (!__any(wide4)) {
+            if (__builtin_amdgcn_ballot_w64(wide4) == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ET_APPEND(qcode[q], qlen[q]);
-            } else if (!__any(wide2)) {
-                // some lane's quad is longer than 32 bits (a long-tailed alphabet: most wavefront rounds have one): that
-                // lane appends that quad as its two pairs, looked up again; everybody else's quads go in whole
+            } else {
+                // some lane's quad is longer than 32 bits (a long-tailed alphabet: most wavefront rounds have one).  Does any of
+                // those lanes hold a PAIR longer than 32 bits, or a partial chunk?  Looked up again here, where it is rare,
+                // rather than tested in every round.
+                bool wide2 = cur.valid != 0xffffu;
+                if (!wide2 && wide4) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (qlen[q] <= 32) {
-                        ET_APPEND(qcode[q], qlen[q]);
-                    } else {
-                        const uint2 e0 = ET_ENTRY(4 * q), e1 = ET_ENTRY(4 * q + 1), e2 = ET_ENTRY(4 * q + 2), e3 = ET_ENTRY(4 * q + 3);
-                        ET_APPEND(e0.x | (e1.x >> (e0.y & 31u)), e0.y + e1.y);
-                        ET_APPEND(e2.x | (e3.x >> (e2.y & 31u)), e2.y + e3.y);
+                    for (int q = 0; q < 4; ++q) {
+                        if (qlen[q] > 32) {
+                            const uint32_t l01 = ET_ENTRY(4 * q).y + ET_ENTRY(4 * q + 1).y;
+                            wide2 = wide2 || l01 > 32 || qlen[q] - l01 > 32;
+                        }
                     }
                 }
-            } else {
-                for (int k = 0; k < 16; ++k) {
-                    uint2 e = ET_ENTRY(k);
-                    if (!((cur.valid >> k) & 1u)) e = make_uint2(0u, 0u);
-                    ET_APPEND(e.x, e.y);
+                if (!__any(wide2)) {
+                    // that lane appends that quad as its two pairs, looked up again; everybody else's quads go in whole
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (qlen[q] <= 32) {
+                            ET_APPEND(qcode[q], qlen[q]);
+                        } else {
+                            const uint2 e0 = ET_ENTRY(4 * q), e1 = ET_ENTRY(4 * q + 1), e2 = ET_ENTRY(4 * q + 2), e3 = ET_ENTRY(4 * q + 3);
+                            ET_APPEND(e0.x | (e1.x >> (e0.y & 31u)), e0.y + e1.y);
+                            ET_APPEND(e2.x | (e3.x >> (e2.y & 31u)), e2.y + e3.y);
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < 16; ++k) {
+                        uint2 e = ET_ENTRY(k);
+                        if (!((cur.valid >> k) & 1u)) e = make_uint2(0u, 0u);
+                        ET_APPEND(e.x, e.y);
+                    }
                 }
             }
 #undef ET_APPEND

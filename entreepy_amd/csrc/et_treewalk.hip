@@ -247,7 +247,10 @@ __device__ __forceinline__ uint32_t tw_seen_before(const uint32_t *__restrict__ 
     return __builtin_amdgcn_readfirstlane(seen);
 }
 
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_tw_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
+#ifndef ET_TW_WAVES_PER_EU
+#define ET_TW_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ET_TW_WAVES_PER_EU, 8))) void k_tw_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs,
                                                     uint32_t n_blocks, const uint16_t *__restrict__ table, uint32_t table_entries, uint32_t n_int,
                                                     uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_start,
                                                     uint32_t *__restrict__ blk_count, uint32_t *__restrict__ changed, uint32_t max_trips,
@@ -530,8 +533,15 @@ void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes,
         seen_dev = dev;
     }
     uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / smem);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-    const uint32_t threads = per_cu == 1 ? 1024u : 512u, waves = threads / 64;
+#ifndef ET_TW_PER_CU_MAX
+#define ET_TW_PER_CU_MAX 3
+#endif
+    per_cu = per_cu < 1 ? 1 : (per_cu > ET_TW_PER_CU_MAX ? ET_TW_PER_CU_MAX : per_cu);
+    // wavefronts per workgroup: what ET_TW_WAVES_PER_EU per SIMD come to on a CU, shared out among its workgroups (<= 16)
+    uint32_t waves = (4u * ET_TW_WAVES_PER_EU + per_cu - 1) / per_cu;
+    if (waves * per_cu > 4u * ET_TW_WAVES_PER_EU) --waves;
+    waves = waves > 16 ? 16 : waves;
+    const uint32_t threads = waves * 64;
     uint32_t grid = static_cast<uint32_t>(cus) * per_cu;
     if (grid > (n_blocks + waves - 1) / waves) grid = (n_blocks + waves - 1) / waves;
     if (worklist && grid > 64) grid = 64;  // a repair sweep: a handful of blocks (workgroups beyond the list leave at once)
