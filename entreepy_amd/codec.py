@@ -186,8 +186,12 @@ class Context:
         """Force the encode tile to rounds x 4 KiB (0 = size-based).  Test/tuning knob."""
         _check(N.lib().et_ctx_set_tile_rounds(self._h, int(rounds)), self._h)
 
+    TIMING_DECODE_BODY = 2  # et_ctx_enable_timing's ET_TIMING_DECODE_BODY: only the decode's write kernel carries events
+
     def enable_timing(self, on=True):
-        _check(N.lib().et_ctx_enable_timing(self._h, int(bool(on))), self._h)
+        """True / False: every phase / nothing carries HIP events; Context.TIMING_DECODE_BODY: the decode's write kernel alone
+        (timings("decode") then holds body_ms, host_ms and the path flags only)."""
+        _check(N.lib().et_ctx_enable_timing(self._h, 2 if (on is not True and on == self.TIMING_DECODE_BODY) else int(bool(on))), self._h)
 
     def timings(self, which=None):
         """Phase timings of the last call (which=None), the last encode-side call ("encode")

@@ -50,7 +50,8 @@ struct et_ctx {
     hipStream_t own_stream = nullptr;
     et::SideLane side = {};  // second lane for the first/last-block launches of a decode
     hipStream_t stream = nullptr;
-    bool timing = false;
+    bool timing = false;       // every phase carries events (et_ctx_enable_timing(ctx, 1))
+    bool timing_body = false;  // only the decode's write kernel does (et_ctx_enable_timing(ctx, ET_TIMING_DECODE_BODY))
     uint32_t force_rpt = 0;
     uint32_t lut_bits_write = et::DEC_LUT_BITS_WRITE;
     uint32_t step_bits = et::DEC_STEP_BITS_DEFAULT;
@@ -184,9 +185,12 @@ Geometry make_geometry(const et_ctx *ctx, const void *d_text, size_t n) {
     g.base = reinterpret_cast<const uint8_t *>(a & ~static_cast<uintptr_t>(15));
     g.lo = a & 15;
     g.hi = g.lo + n;
-    // Aim for >= 8192 tiles (32 per CU) before growing the tile towards 64 KiB.
+    // Aim for >= 2048 tiles (one per resident K4 workgroup) before growing the tile towards 512 KiB: 1 GiB is 2048 tiles of
+    // 512 KiB.  A tile costs K1 a flush of its 32 counter replicas between two barriers and K4 a shared seam word and a
+    // restart of its ring; with 64 KiB tiles (round 2: 16384 of them for 1 GiB) that was ~2 % of a step (775-780 -> 792-797 GB/s),
+    // and the tile scan reads 2 MiB of tile histograms instead of 16.
     uint32_t rpt = 1;
-    while (rpt < et::MAX_ROUNDS_PER_TILE && g.hi / (static_cast<uint64_t>(rpt) * et::ROUND_BYTES) > 8192) rpt <<= 1;
+    while (rpt < et::MAX_ROUNDS_PER_TILE && g.hi / (static_cast<uint64_t>(rpt) * et::ROUND_BYTES) > 2048) rpt <<= 1;
     if (ctx && ctx->force_rpt) rpt = ctx->force_rpt;
     g.rpt = rpt;
     const uint64_t tile_bytes = static_cast<uint64_t>(rpt) * et::ROUND_BYTES;
@@ -227,6 +231,16 @@ constexpr int EV_DEC = 6;
 et::KernelEvents timed(et_ctx *ctx, int a, int b) {
     et::KernelEvents e;
     if (ctx->timing) {
+        e.start = ctx->ev[a];
+        e.stop = ctx->ev[b];
+    }
+    return e;
+}
+
+// The decode's write kernel: also when it alone is timed.
+et::KernelEvents timed_body(et_ctx *ctx, int a, int b) {
+    et::KernelEvents e;
+    if (ctx->timing || ctx->timing_body) {
         e.start = ctx->ev[a];
         e.stop = ctx->ev[b];
     }
@@ -419,7 +433,9 @@ extern "C" int et_ctx_set_tile_rounds(et_ctx *ctx, uint32_t rounds) {
 
 extern "C" int et_ctx_enable_timing(et_ctx *ctx, int on) {
     if (!ctx) return ET_ERR_ARG;
-    ctx->timing = on != 0;
+    ctx->timing = on != 0 && on != ET_TIMING_DECODE_BODY;
+    ctx->timing_body = on == ET_TIMING_DECODE_BODY;
+    ctx->pend_enc = ctx->pend_dec = false;  // (what an earlier mode left to be worked out is gone with its events)
     return ET_OK;
 }
 
@@ -435,6 +451,11 @@ extern "C" int et_last_timings_of(et_ctx *ctx, int which, et_timings *out) {
         ctx->tm_enc.scan_ms = ctx->pend_enc_bits ? elapsed(ctx, 1, 2) : 0.f;  // everything between K1 and K4: histogram reduce, host code construction, tile scan, uploads
         ctx->tm_enc.body_ms = elapsed(ctx, 2, 3);
         ctx->pend_enc = ctx->pend_enc_shard = false;
+    }
+    if (which == 1 && ctx->pend_dec && ctx->timing_body) {  // the write kernel's own pair is all there is
+        ET_HIP(hipEventSynchronize(ctx->ev[EV_DEC + 3]));
+        ctx->tm_dec.body_ms = elapsed(ctx, EV_DEC + 2, EV_DEC + 3);
+        ctx->pend_dec = false;
     }
     if (which == 1 && ctx->pend_dec) {
         ET_HIP(hipEventSynchronize(ctx->ev[EV_DEC + 3]));
@@ -1050,7 +1071,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
         // speculative: the kernel itself looks at the sweeps' flags and does nothing if the state is not final
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
-                             write_ticket_zero, speculative ? flag : nullptr, timed(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain, cb->max_length);
+                             write_ticket_zero, speculative ? flag : nullptr, timed_body(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain, cb->max_length);
         write_ticket_zero = false;
         ET_HIP(hipGetLastError());
         return ET_OK;
@@ -1162,7 +1183,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
     if (n_out && !wrote) ET_TRY(write_symbols(n_out, false));
     *out_len = static_cast<size_t>(n_out);
-    if (ctx->timing) {
+    if (ctx->timing || ctx->timing_body) {
         ctx->tm_dec = et_timings{};
         ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
         ctx->tm_dec.sync_iters = iters;

@@ -10,7 +10,7 @@ namespace et {
 
 constexpr int BLOCK = 256;                    // threads per workgroup: 4 wavefronts of 64
 constexpr uint32_t ROUND_BYTES = BLOCK * 16;  // one 16-byte load per lane
-constexpr uint32_t MAX_ROUNDS_PER_TILE = 16;  // tile <= 64 KiB (u32 tile counters, u32 bit cursors)
+constexpr uint32_t MAX_ROUNDS_PER_TILE = 128;  // tile <= 512 KiB (u32 tile counters; u32 bit cursors: 2^19 symbols of <= 255 bits)
 constexpr uint32_t HIST_REDUCE_GROUPS = 128;   // k_hist_reduce: two histogram columns each
 constexpr uint32_t MAX_GRID = 2048;           // 256 CUs x 8 workgroups, grid-stride beyond
 

@@ -2134,7 +2134,9 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
     const uint32_t tab_bytes = (n_entries * 8u + 15u) & ~15u;
     uint32_t *scratch = reinterpret_cast<uint32_t *>(dec_smem_raw + tab_bytes);
     constexpr uint32_t SCRATCH_WORDS = 2 * HALVES * 4 + 4;
-    const int tid = threadIdx.x, half = tid / BLOCK, htid = tid % BLOCK, wave = htid >> 6;
+    // (which half and which wavefront: scalars, so that the blocks' plans below -- offsets, totals, windows -- are worked out on the
+    // scalar unit instead of by every lane)
+    const int tid = threadIdx.x, half = __builtin_amdgcn_readfirstlane(tid / BLOCK), htid = tid % BLOCK, wave = __builtin_amdgcn_readfirstlane(htid >> 6);
     const uint32_t stage_off = tab_bytes + SCRATCH_WORDS * 4 + half * (DEC_STAGE_BYTES + 16);
     uint8_t *smem8 = reinterpret_cast<uint8_t *>(dec_smem_raw);
     uint8_t *stage = smem8 + stage_off;
@@ -2151,11 +2153,11 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
         __syncthreads();  // tables staged (first trip); everybody is done with the ticket word and the stages
         if (tid == 0) scratch[2 * HALVES * 4] = atomicAdd(ticket, CH_CHUNK);
         __syncthreads();
-        const uint64_t b0 = scratch[2 * HALVES * 4];
+        const uint64_t b0 = __builtin_amdgcn_readfirstlane(scratch[2 * HALVES * 4]);
         if (b0 >= n_blocks) break;
         const uint64_t b1 = b0 + CH_CHUNK < n_blocks ? b0 + CH_CHUNK : n_blocks;
         for (uint64_t bb = b0; bb < b1; bb += HALVES) {
-            // every thread works out every half's plan, so that the barriers below are the same for all
+            // every wavefront works out every half's plan, so that the barriers below are the same for all
             // (all blocks are this kernel's: a lane's window starts at its own first word, so the stream's first block is
             // like any other; the one or two blocks the stream ends in load their words guarded and clip what the pad
             // bits behind the last codeword decode to)
@@ -2198,7 +2200,7 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
             uint32_t total_of[HALVES], n_win = 0;
 #pragma unroll
             for (int h = 0; h < HALVES; ++h) {
-                total_of[h] = totals[h * 4] + totals[h * 4 + 1] + totals[h * 4 + 2] + totals[h * 4 + 3];
+                total_of[h] = __builtin_amdgcn_readfirstlane(totals[h * 4] + totals[h * 4 + 1] + totals[h * 4 + 2] + totals[h * 4 + 3]);
                 uint64_t o1 = o0_of[h] + total_of[h];
                 if (o1 > n_symbols) o1 = n_symbols;
                 const uint32_t span = act_of[h] ? static_cast<uint32_t>(o0_of[h] & 15) + static_cast<uint32_t>(o1 - o0_of[h]) : 0u;

@@ -87,14 +87,19 @@ int et_ctx_device(const et_ctx *ctx);
 /* Pre-size workspaces for inputs of up to max_text_bytes so that no allocation
  * happens inside a timed call. */
 int et_ctx_reserve(et_ctx *ctx, size_t max_text_bytes);
-/* Tuning/test knob: force the encode tile to `rounds` x 4 KiB (1, 2, 4, 8 or 16);
+/* Tuning/test knob: force the encode tile to `rounds` x 4 KiB (a power of two, 1 .. 128);
  * 0 restores the size-based choice.  Results never depend on it. */
 int et_ctx_set_tile_rounds(et_ctx *ctx, uint32_t rounds);
 /* Record per-phase HIP events (small overhead); off by default.  The calls stay as
  * asynchronous as they are without: the event arithmetic happens in et_last_timings[_of],
  * which waits for the call's last event.  et_last_timings = the last call's; _of: which =
  * 0 the last encode-side call, 1 the last decode (separate event sets, so the encode
- * figures can be fetched after the decode that followed has been enqueued). */
+ * figures can be fetched after the decode that followed has been enqueued).
+ * on = ET_TIMING_DECODE_BODY: only the decode's write kernel carries its pair of events (a
+ * dispatch that carries events costs ~5 us of queue time on either side of it: ~35 us of a
+ * 1.4 ms step with all four large kernels timed); et_timings then holds body_ms, host_ms,
+ * sync_iters and the flags, everything else 0. */
+#define ET_TIMING_DECODE_BODY 2
 int et_ctx_enable_timing(et_ctx *ctx, int on);
 int et_last_timings(et_ctx *ctx, et_timings *out);
 int et_last_timings_of(et_ctx *ctx, int which, et_timings *out);

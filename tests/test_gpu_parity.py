@@ -247,10 +247,10 @@ def test_virtual_shards_concat(ctx, shards):
     assert file_img[: (bit + 7) // 8].tobytes() == want
 
 
-@pytest.mark.parametrize("rounds", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("rounds", [1, 2, 4, 8, 16, 32, 64, 128])
 @pytest.mark.parametrize("n", [70001, (3 << 20) + 77])
 def test_every_tile_geometry(ctx, rounds, n):
-    """Tiles of 1..16 rounds (the size-based choice reaches 16 only at ~1 GiB)."""
+    """Tiles of 1..128 rounds = 4 .. 512 KiB (the size-based choice reaches 128 only at 1 GiB)."""
     ctx.set_tile_rounds(rounds)
     try:
         _roundtrip(ctx, corpus.text_like(n, seed=rounds * 1000 + 7))
