@@ -27,6 +27,27 @@
 
 namespace et {
 
+// Non-temporal accesses, per kernel (measured r03, text-1G, ms): K1's loads of the text 0.218 -> 0.173 (the histogram pass was
+// held up by the cache lines it left behind, not by its ds_add rate); D3's stores of the output 0.495 -> 0.490, and the text is
+// not pushed out of the caches by the output in front of the next K1.  NOT: K4's stores (its rounds end mid-line: 0.37 -> 0.40,
+// also with flushes cut at 128-byte lines), K4's loads (K4 0.37 -> 0.365 but D1 behind it 0.187 -> 0.20), D1's and D3's loads
+// (their lanes share lines: 0.187 -> 0.29, 0.49 -> 0.53).
+#ifndef ET_NT_LOAD_K1
+#define ET_NT_LOAD_K1 1
+#endif
+#ifndef ET_NT_LOAD_K4
+#define ET_NT_LOAD_K4 0
+#endif
+#ifndef ET_NT_STORE_K4
+#define ET_NT_STORE_K4 0
+#endif
+#ifndef ET_NT_STORE_D3
+#define ET_NT_STORE_D3 1
+#endif
+#ifndef ET_NT_LOAD_D3
+#define ET_NT_LOAD_D3 0
+#endif
+
 // --------------------------------------------------------------------------------
 // wavefront / workgroup scans (DPP, no LDS traffic inside a wavefront)
 // --------------------------------------------------------------------------------
@@ -111,10 +132,15 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t *__restrict__ base, ui
 
 // Tile-level version: `interior` (workgroup-uniform, so a scalar branch) says the whole
 // tile lies inside the stream and every chunk of it is a plain 16-byte load.
+// NT: a non-temporal load (the text is read once per pass: nothing of it is worth a cache line)
+template <bool NT = false>
 __device__ __forceinline__ Chunk load_chunk_in_tile(const uint8_t *__restrict__ base, uint64_t off, uint64_t lo, uint64_t hi, bool interior) {
     if (interior) {
         Chunk c;
-        const uint4 v = *reinterpret_cast<const uint4 *>(base + off);
+        typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+        u32x4_nt v;
+        if (NT) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt *>(base + off));
+        else v = *reinterpret_cast<const u32x4_nt *>(base + off);
         c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
         c.valid = 0xffffu;
         return c;
@@ -166,7 +192,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_tiles(const uint8_t *__rest
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 c[u].valid = 0;
-                if (c0 + u * HIST_BLOCK < tile_chunks) c[u] = load_chunk_in_tile(base, t0 + static_cast<uint64_t>(c0 + u * HIST_BLOCK) * 16, lo, hi, interior);
+                if (c0 + u * HIST_BLOCK < tile_chunks) c[u] = load_chunk_in_tile<ET_NT_LOAD_K1>(base, t0 + static_cast<uint64_t>(c0 + u * HIST_BLOCK) * 16, lo, hi, interior);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -450,7 +476,11 @@ __device__ __forceinline__ void flush_words(const RingFlush &f, uint32_t from, u
         const uint32_t v = __builtin_bswap32(f.ring[slot]);
         f.ring[slot] = 0;
         if (i == 0 && f.first_word_shared) atomicOr(f.out32, v);
+#if ET_NT_STORE_K4
+        else __builtin_nontemporal_store(v, f.out32 + i);
+#else
         else f.out32[i] = v;
+#endif
     }
 }
 
@@ -479,12 +509,12 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
         const uint64_t t0 = static_cast<uint64_t>(t) * tile_bytes + static_cast<uint64_t>(tid) * 16;
         const bool interior = static_cast<uint64_t>(t) * tile_bytes >= lo && static_cast<uint64_t>(t + 1) * tile_bytes <= hi;
 
-        Chunk cur = load_chunk_in_tile(base, t0, lo, hi, interior);
+        Chunk cur = load_chunk_in_tile<ET_NT_LOAD_K4>(base, t0, lo, hi, interior);
         for (uint32_t r = 0; r < rounds_per_tile; ++r) {
             Chunk nxt;
             nxt.valid = 0;
             nxt.w[0] = nxt.w[1] = nxt.w[2] = nxt.w[3] = 0;
-            if (r + 1 < rounds_per_tile) nxt = load_chunk_in_tile(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi, interior);
+            if (r + 1 < rounds_per_tile) nxt = load_chunk_in_tile<ET_NT_LOAD_K4>(base, t0 + static_cast<uint64_t>(r + 1) * ROUND_BYTES, lo, hi, interior);
 
             // Symbols are merged before the append step: neighbours into pairs, pairs into
             // quads of la + lb + lc + ld bits.  A group only fails to fit 32 bits when long
@@ -1571,7 +1601,7 @@ template <bool WITH_RUN_IN>
 __device__ __forceinline__ void load_window(uint32_t (&W)[RW_WORDS], const uint32_t *__restrict__ words, uint64_t sub_g) {
     const uint32_t *src = words + sub_g * (SUB_BITS / 32) - 4;
 #pragma unroll
-    for (int j = WITH_RUN_IN ? 0 : 4; j < RW_WORDS; ++j) W[j] = __builtin_bswap32(src[j]);
+    for (int j = WITH_RUN_IN ? 0 : 4; j < RW_WORDS; ++j) W[j] = __builtin_bswap32(ET_NT_LOAD_D3 && !WITH_RUN_IN ? __builtin_nontemporal_load(src + j) : src[j]);
     if (!WITH_RUN_IN) W[0] = W[1] = W[2] = W[3] = 0;
 }
 
@@ -2234,7 +2264,14 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
                     const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
                     for (uint32_t g = win + htid * 16; g < win_hi; g += BLOCK * 16) {
                         if (g >= lo_valid && g + 16 <= win_hi) {
+#if ET_NT_STORE_D3
+                            {
+                                typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store(*reinterpret_cast<const u32x4_nt *>(stage + (g - win)), reinterpret_cast<u32x4_nt *>(out_base + g));
+                            }
+#else
                             *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(stage + (g - win));
+#endif
                         } else {
                             for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = stage[k - win];
                         }
