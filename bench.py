@@ -202,7 +202,7 @@ def main():
         phases["dec_total"] += t["total_ms"]
         phases["sync_launches"] += t["sync_iters"]
         state["sync_kernel"] = "k_tw_sync" if t["tree_walk_sync"] else "k_dec_sync_reg2"
-        state["write_kernel"] = "k_dec_write_chain" if t["chained_write"] else "k_dec_write_reg"
+        state["write_kernel"] = "k_dec_write_wave" if t["chained_write"] else "k_dec_write_reg"
 
     # The HIP events of every call are recorded inside the timed region; their elapsed
     # times are READ where reading cannot stall the stream: the decode's after the next

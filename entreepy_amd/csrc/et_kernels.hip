@@ -41,12 +41,6 @@ namespace et {
 #ifndef ET_NT_STORE_K4
 #define ET_NT_STORE_K4 0
 #endif
-#ifndef ET_NT_STORE_D3
-#define ET_NT_STORE_D3 1
-#endif
-#ifndef ET_NT_LOAD_D3
-#define ET_NT_LOAD_D3 0
-#endif
 
 // --------------------------------------------------------------------------------
 // wavefront / workgroup scans (DPP, no LDS traffic inside a wavefront)
@@ -1601,7 +1595,7 @@ template <bool WITH_RUN_IN>
 __device__ __forceinline__ void load_window(uint32_t (&W)[RW_WORDS], const uint32_t *__restrict__ words, uint64_t sub_g) {
     const uint32_t *src = words + sub_g * (SUB_BITS / 32) - 4;
 #pragma unroll
-    for (int j = WITH_RUN_IN ? 0 : 4; j < RW_WORDS; ++j) W[j] = __builtin_bswap32(ET_NT_LOAD_D3 && !WITH_RUN_IN ? __builtin_nontemporal_load(src + j) : src[j]);
+    for (int j = WITH_RUN_IN ? 0 : 4; j < RW_WORDS; ++j) W[j] = __builtin_bswap32(src[j]);
     if (!WITH_RUN_IN) W[0] = W[1] = W[2] = W[3] = 0;
 }
 
@@ -2149,69 +2143,78 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
 #undef CH_G
 }
 
-// HALVES x 256 threads: every 256 take one 8 KiB block (as k_dec_write_reg's workgroup does) and share the tables --
-// 16 KiB for the root alone, which one block's stage beside it would hold a CU to 4 workgroups of 4 wavefronts.
-constexpr uint32_t CH_CHUNK = 4;  // blocks per ticket (2: 1 % slower, 8: the same)
-template <int HALVES>
-__global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
-                                                                   const uint2 *__restrict__ chain, uint32_t n_entries,
-                                                                   const uint32_t *__restrict__ sub_state, const unsigned long long *__restrict__ blk_off,
-                                                                   uint64_t n_symbols, uint8_t *__restrict__ out, uint32_t *__restrict__ ticket,
-                                                                   const uint32_t *__restrict__ void_flags, uint64_t n_subs, uint32_t max_len) {
+// ---------------------------------------------------------------------------------------------------------
+// D3 with wavefronts that own their work end to end (as D1's do): a wavefront takes a QUARTER of an 8 KiB block -- 64
+// subsequences, ~3.5 K symbols of text -- works out where its output begins from the four quarters' counts (four loads and
+// a DPP reduction instead of an LDS exchange behind a barrier), walks into a stage of its own and stores its own bytes of
+// the output: whole 16-byte chunks as such, the two chunks it shares with its neighbours one byte per lane.  Nothing is
+// shared after the tables are staged: no barrier, no ticket -- quarters are dealt out by wavefront number.
+// (Rounds 2-3 had a workgroup of 512 threads per two blocks here, k_dec_write_chain: a trip was a serial chain -- ticket
+// atomic, loads, scan, barrier, walk, barrier, stores, barrier -- that three workgroups per CU could not cover; without its
+// walk that kernel still took 0.33 of its 0.49 ms.  24 wavefronts per CU are 24 chains: 0.49 -> 0.445 ms, of which the
+// output stores and loads alone, in this pattern, are 0.36 -- the mixed-traffic floor of the HBM, ~5 TB/s -- and the walk
+// alone 0.42.  With tickets of 8 blocks per workgroup, one barrier pair per ticket: 0.442-0.468, no better than dealt out.)
+constexpr uint32_t WV_STAGE = DEC_STAGE_BYTES / 4;  // bytes of output a wavefront stages at once (a block's stage, quartered)
+constexpr uint32_t WV_STAGE_ALLOC = WV_STAGE + 32;
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return __builtin_amdgcn_readlane(wave_inclusive_scan(x), 63); }
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
+                                                              const uint2 *__restrict__ chain, uint32_t n_entries,
+                                                              const uint32_t *__restrict__ sub_state, const unsigned long long *__restrict__ blk_off,
+                                                              uint64_t n_symbols, uint8_t *__restrict__ out,
+                                                              const uint32_t *__restrict__ void_flags, uint64_t n_subs, uint32_t max_len) {
     if (void_flags && !dec_state_final(void_flags[1], void_flags[2], n_blocks)) return;  // see k_dec_write_reg
-    // LDS: tables | wave totals [2][HALVES][4], ticket | HALVES stages
+    // LDS: tables | WAVES stages
     uint2 *tab = reinterpret_cast<uint2 *>(dec_smem_raw);
     const uint32_t tab_bytes = (n_entries * 8u + 15u) & ~15u;
-    uint32_t *scratch = reinterpret_cast<uint32_t *>(dec_smem_raw + tab_bytes);
-    constexpr uint32_t SCRATCH_WORDS = 2 * HALVES * 4 + 4;
-    // (which half and which wavefront: scalars, so that the blocks' plans below -- offsets, totals, windows -- are worked out on the
-    // scalar unit instead of by every lane)
-    const int tid = threadIdx.x, half = __builtin_amdgcn_readfirstlane(tid / BLOCK), htid = tid % BLOCK, wave = __builtin_amdgcn_readfirstlane(htid >> 6);
-    const uint32_t stage_off = tab_bytes + SCRATCH_WORDS * 4 + half * (DEC_STAGE_BYTES + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t stage_off = tab_bytes + wv * WV_STAGE_ALLOC;
     uint8_t *smem8 = reinterpret_cast<uint8_t *>(dec_smem_raw);
     uint8_t *stage = smem8 + stage_off;
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)dec_smem_raw));
     const uint32_t lds_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)stage));
-    for (uint32_t i = tid; i < n_entries; i += BLOCK * HALVES) {
+    for (uint32_t i = tid; i < n_entries; i += 64 * WAVES) {
         uint2 v = chain[i];
         v.y += lds_tab;  // next-table offsets -> LDS addresses
         tab[i] = v;
     }
     const ChainWalk cw = {lds_tab | ((32u - CH_ROOT_BITS) << 24), lds_tab, max_len >= 32};
-    uint32_t parity = 0;
-    for (;;) {
-        __syncthreads();  // tables staged (first trip); everybody is done with the ticket word and the stages
-        if (tid == 0) scratch[2 * HALVES * 4] = atomicAdd(ticket, CH_CHUNK);
-        __syncthreads();
-        const uint64_t b0 = __builtin_amdgcn_readfirstlane(scratch[2 * HALVES * 4]);
-        if (b0 >= n_blocks) break;
-        const uint64_t b1 = b0 + CH_CHUNK < n_blocks ? b0 + CH_CHUNK : n_blocks;
-        for (uint64_t bb = b0; bb < b1; bb += HALVES) {
-            // every wavefront works out every half's plan, so that the barriers below are the same for all
-            // (all blocks are this kernel's: a lane's window starts at its own first word, so the stream's first block is
-            // like any other; the one or two blocks the stream ends in load their words guarded and clip what the pad
-            // bits behind the last codeword decode to)
-            uint64_t o0_of[HALVES];
-            bool act_of[HALVES], edge_of[HALVES], any = false;
+    __syncthreads();  // tables staged
+    {
+        for (uint32_t u = blockIdx.x * WAVES + wv; u < n_blocks * 4; u += gridDim.x * WAVES) {
+            const uint64_t b = u >> 2;
+            const uint32_t quarter = u & 3u;
+            const uint64_t o0 = blk_off[b];
+            if (o0 >= n_symbols) continue;  // pad bits decoded past the declared length
+            const bool edge = block_limit(n_bytes, b) != 0xffffffffu;
+            // the four quarters' counts (the same lane of each): where this one's output begins
+            uint32_t before = 0, st = 0;
 #pragma unroll
-            for (int h = 0; h < HALVES; ++h) {
-                const uint64_t bh = bb + h;
-                act_of[h] = bh < b1;
-                edge_of[h] = act_of[h] && block_limit(n_bytes, bh) != 0xffffffffu;
-                o0_of[h] = act_of[h] ? blk_off[bh] : 0;
-                if (o0_of[h] >= n_symbols) act_of[h] = false;  // pad bits decoded past the declared length
-                any = any || act_of[h];
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint64_t sg = b * BLOCK + q * 64 + lane;
+                const uint32_t v = sg < n_subs ? sub_state[sg] : 0u;
+                if (q == quarter) st = v;
+                if (q < quarter) before += v >> 16;
             }
-            if (!any) continue;
-            const bool mine = act_of[half];
-            const uint64_t sub_g = (bb + half) * BLOCK + htid;
-            uint32_t start = 0, count = 0;
+            before = wave_sum(before);
+            const uint64_t sub_g = b * BLOCK + quarter * 64 + lane;
+            const uint32_t start = st & 31u;  // (a start is < 32 in a settled state; masked so that nothing else can reach the walk)
+            const uint32_t count = st >> 16;
+            const uint32_t inc = wave_inclusive_scan(count);
+            const uint32_t wave_total = __builtin_amdgcn_readlane(inc, 63), my_off = inc - count;
+            const uint64_t ow = o0 + before;  // the wavefront's first symbol
+            if (ow >= n_symbols || wave_total == 0) continue;
+            uint64_t o1 = ow + wave_total;
+            if (o1 > n_symbols) o1 = n_symbols;
+            const uint32_t n_out = static_cast<uint32_t>(o1 - ow);
+            const uint32_t phase = static_cast<uint32_t>(ow & 15);  // stage offset of the first symbol
+            const uint32_t span = phase + n_out;
+            uint8_t *out_base = out + (ow - phase);
             uint32_t W[RW_WORDS];
-            if (mine && sub_g < n_subs) {
-                const uint32_t st = sub_state[sub_g];
-                start = st & 31u;  // (a start is < 32 in a settled state; masked so that nothing else can reach the walk)
-                count = st >> 16;
-                if (edge_of[half]) {
+            if (sub_g < n_subs) {
+                if (edge) {
                     W[0] = W[1] = W[2] = W[3] = 0;
 #pragma unroll
                     for (int j = 4; j < RW_WORDS; ++j) W[j] = load_be32_guarded(words, sub_g * (SUB_BITS / 32) - 4 + j, n_bytes);
@@ -2222,62 +2225,31 @@ __global__ __launch_bounds__(BLOCK *HALVES) void k_dec_write_chain(const uint32_
 #pragma unroll
                 for (int j = 0; j < RW_WORDS; ++j) W[j] = 0;
             }
-            uint32_t *totals = scratch + parity * (HALVES * 4);
-            parity ^= 1u;
-            const uint32_t inc = wave_inclusive_scan(count);
-            if ((htid & 63) == 63) totals[half * 4 + wave] = inc;
-            __syncthreads();
-            uint32_t total_of[HALVES], n_win = 0;
-#pragma unroll
-            for (int h = 0; h < HALVES; ++h) {
-                total_of[h] = __builtin_amdgcn_readfirstlane(totals[h * 4] + totals[h * 4 + 1] + totals[h * 4 + 2] + totals[h * 4 + 3]);
-                uint64_t o1 = o0_of[h] + total_of[h];
-                if (o1 > n_symbols) o1 = n_symbols;
-                const uint32_t span = act_of[h] ? static_cast<uint32_t>(o0_of[h] & 15) + static_cast<uint32_t>(o1 - o0_of[h]) : 0u;
-                const uint32_t wins = (span + DEC_STAGE_BYTES - 1) / DEC_STAGE_BYTES;
-                n_win = wins > n_win ? wins : n_win;
-            }
-            uint32_t my_off = inc - count;
-            for (int w = 0; w < wave; ++w) my_off += totals[half * 4 + w];
-            const uint64_t o0 = o0_of[half];
-            const uint32_t block_total = total_of[half];
-            uint64_t o1 = o0 + block_total;
-            if (o1 > n_symbols) o1 = n_symbols;
-            const uint32_t n_out = mine ? static_cast<uint32_t>(o1 - o0) : 0u;
-            const uint32_t phase = static_cast<uint32_t>(o0 & 15);  // stage offset of the first symbol
-            const uint32_t span = mine ? phase + n_out : 0u;
-            uint8_t *out_base = out + (o0 - phase);
-            const bool one_window = phase + block_total <= DEC_STAGE_BYTES && n_out == block_total && !edge_of[half];
-            for (uint32_t wi = 0; wi < n_win; ++wi) {
-                const uint32_t win = wi * DEC_STAGE_BYTES;
-                const uint32_t win_hi = min(win + DEC_STAGE_BYTES, span);
-                if (win < span) {
-                    const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
-                    if (one_window) {
-                        if (count) walk_write_chain<1>(cw, smem8, W, start, lds_stage + my_lo - 1u, 0, 0, 0);
-                    } else if (my_lo < win_hi && my_hi > win) {
-                        walk_write_chain<2>(cw, smem8, W, start, my_lo, win, win_hi, stage_off);
+            const bool one_window = phase + wave_total <= WV_STAGE && n_out == wave_total && !edge;
+            const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
+            for (uint32_t win = 0; win < span; win += WV_STAGE) {
+                const uint32_t win_hi = min(win + WV_STAGE, span);
+                if (one_window) {
+                    if (count) walk_write_chain<1>(cw, smem8, W, start, lds_stage + my_lo - 1u, 0, 0, 0);
+                } else if (my_lo < win_hi && my_hi > win) {
+                    walk_write_chain<2>(cw, smem8, W, start, my_lo, win, win_hi, stage_off);
+                }
+                // (the wavefront's own LDS stores, then its own loads: in order, no barrier)
+                const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
+                for (uint32_t g = win + lane * 16; g < win_hi; g += 64 * 16) {
+                    if (g >= lo_valid && g + 16 <= win_hi) {
+                        typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+                        // (non-temporal: plain stores cost this kernel nothing, but the NEXT encode's K4 6 % -- 0.392 against 0.370)
+                        __builtin_nontemporal_store(*reinterpret_cast<const u32x4_nt *>(stage + (g - win)), reinterpret_cast<u32x4_nt *>(out_base + g));
                     }
                 }
-                __syncthreads();
-                if (win < span) {
-                    const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
-                    for (uint32_t g = win + htid * 16; g < win_hi; g += BLOCK * 16) {
-                        if (g >= lo_valid && g + 16 <= win_hi) {
-#if ET_NT_STORE_D3
-                            {
-                                typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-                                __builtin_nontemporal_store(*reinterpret_cast<const u32x4_nt *>(stage + (g - win)), reinterpret_cast<u32x4_nt *>(out_base + g));
-                            }
-#else
-                            *reinterpret_cast<uint4 *>(out_base + g) = *reinterpret_cast<const uint4 *>(stage + (g - win));
-#endif
-                        } else {
-                            for (uint32_t k = max(g, lo_valid); k < min(g + 16, win_hi); ++k) out_base[k] = stage[k - win];
-                        }
-                    }
+                // the two chunks the wavefront shares with its neighbours (or the window's ends): its own bytes only, one per lane
+                {
+                    const uint32_t head = lo_valid & ~15u, tail = win_hi & ~15u;
+                    const uint32_t pos = (lane < 16 ? head : tail) + (lane & 15u);
+                    const bool partial = lane < 16 ? (lo_valid & 15u) != 0 : (win_hi & 15u) != 0;  // (one chunk for both: its bytes are stored twice)
+                    if (lane < 32 && partial && pos >= lo_valid && pos < win_hi) out_base[pos] = stage[pos - win];
                 }
-                __syncthreads();
             }
         }
     }
@@ -2729,14 +2701,15 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero,
                       const uint32_t *void_flags, KernelEvents ev, const uint64_t *chain, uint32_t n_chain, uint32_t chain_max_len) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
-    if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-    if (chain) {  // every block, one launch, no side lane; `tb` is not looked at
-        constexpr int HALVES = 2;  // (1: 0.565 ms per GiB of text, 3: 0.54, against 0.509)
-        const uint32_t n_chunks_ch = (n_blocks + CH_CHUNK - 1) / CH_CHUNK;
-        const size_t smem_chain = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + (2 * HALVES * 4 + 4) * sizeof(uint32_t) + HALVES * (DEC_STAGE_BYTES + 16);
-        ET_LAUNCH_TIMED(k_dec_write_chain<HALVES>, dim3(decode_grid(k_dec_write_chain<HALVES>, smem_chain, n_chunks_ch, true, BLOCK * HALVES)), dim3(BLOCK * HALVES), smem_chain, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, ticket, void_flags, n_subs, chain_max_len);
+    if (chain) {  // every block, one launch, no side lane, no ticket; `tb` is not looked at
+        // 8 wavefronts per workgroup share the tables (17 KiB) beside their 4 KiB stages: 3 workgroups = 24 wavefronts per CU
+        constexpr int WAVES = 8;
+        const size_t smem_wave = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + WAVES * WV_STAGE_ALLOC;
+        const uint32_t n_units = (n_blocks * 4 + WAVES - 1) / WAVES;
+        ET_LAUNCH_TIMED(k_dec_write_wave<WAVES>, dim3(decode_grid(k_dec_write_wave<WAVES>, smem_wave, n_units, true, 64 * WAVES)), dim3(64 * WAVES), smem_wave, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, void_flags, n_subs, chain_max_len);
         return;
     }
+    if (!ticket_is_zero) (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     const uint32_t n_chunks = (n_blocks + WRITE_CHUNK - 1) / WRITE_CHUNK;
     const size_t smem = decode_smem_bytes(tb, true, false);
     if (use_reg_kernels(n_blocks)) {

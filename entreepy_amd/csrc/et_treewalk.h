@@ -56,7 +56,7 @@ ET_TW_HD inline uint32_t tw_rows(uint32_t n_int) { return n_int + TW_ENTRY_ROWS;
 ET_TW_HD inline uint32_t tw_table_entries(uint32_t n_int) { return tw_rows(n_int) << 8; }
 
 // ---------------------------------------------------------------------------------------------------------
-// Chained lookup tables for the WRITE walk (D3, k_dec_write_chain in et_kernels.hip).  decode.zig:143-203 again:
+// Chained lookup tables for the WRITE walk (D3, k_dec_write_wave in et_kernels.hip).  decode.zig:143-203 again:
 // the greedy walk looks up to two whole codewords up per step in a table indexed by the next CH_ROOT_BITS bits.
 // A code longer than the index used to be an "escape" that threw its lane out of the wavefront's lockstep loop;
 // on a long-tailed alphabet one wavefront step in three contains one.  Here such an index is an ordinary entry --

@@ -314,11 +314,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ET_TW_WAVE
             const long long w0 = static_cast<long long>(q[u]) * 16 - TW_RUN;
             if (!edge) {
 #pragma unroll
-#ifdef ET_NT_LOAD_D1
-                for (int j = 0; j < TW_WORDS; ++j) W[u][j] = __builtin_nontemporal_load(words + w0 + j);
-#else
                 for (int j = 0; j < TW_WORDS; ++j) W[u][j] = words[w0 + j];  // (as they lie in memory: no byte swap, see tw_walk)
-#endif
             } else {
 #pragma unroll
                 for (int j = 0; j < TW_WORDS; ++j) W[u][j] = tw_load_guarded(words, w0 + j, n_bytes, (mode & TW_FRONT_OK) != 0);

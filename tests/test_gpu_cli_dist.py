@@ -424,10 +424,10 @@ def test_bench_line_has_the_contract_keys():
     assert abs(d["value"] - (32 << 20) / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["kernel"] in d["kernels"] and "k_tw_sync" in d["kernels"] and "k_dec_write_chain" in d["kernels"]
+    assert rf["kernel"] in d["kernels"] and "k_tw_sync" in d["kernels"] and "k_dec_write_wave" in d["kernels"]
     # the dominant kernel's duration comes from the events it carries through the TIMED region (the other phases' from the
     # instrumented set-up steps, and the line says so)
-    assert rf["kernel"] != "k_dec_write_chain" or "timed region" in rf["measured"]
+    assert rf["kernel"] != "k_dec_write_wave" or "timed region" in rf["measured"]
     assert "phase_ms_measured" in d and all(d["phase_ms"][k] > 0 for k in ("hist", "enc_body", "dec_sync_first", "dec_body"))
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
     assert "error" not in d["workloads"]["enwik-like"] and d["workloads"]["enwik-like"]["round_trip_GBps"] > 0

@@ -762,7 +762,7 @@ def test_tree_walk_sync_is_what_a_decode_runs(ctx):
 
 
 def test_chained_write_windows_and_long_codes(ctx):
-    """The write pass over chained lookup tables (k_dec_write_chain) where its special paths are: blocks that hold
+    """The write pass over chained lookup tables (k_dec_write_wave) where its special paths are: blocks that hold
     more symbols than the LDS stage (1- and 2-bit codes: up to four windows per block), a long-tailed alphabet whose
     rare symbols take two to four chained lookups, the same with the rare symbols made frequent in the STREAM (every
     lane meets several, also as its last codeword), and streams cut inside the last block."""

@@ -8,7 +8,7 @@ timeout -k 10 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISS
 python3 $R/tools/pmc_summary.py $R/gpurun_out | python3 -c "
 import json,sys
 d=json.load(sys.stdin)
-for k in ('k_tw_sync','k_dec_write_chain','k_encode_tiles','k_hist_tiles'):
+for k in ('k_tw_sync','k_dec_write_wave','k_encode_tiles','k_hist_tiles'):
     v=d.get(k,{})
     print(k, {c:round(x) for c,x in v.items() if c.startswith('SQC') or c in ('SQ_IFETCH','SQ_INSTS_VALU','SQ_WAIT_INST_ANY')})
 "
