@@ -673,6 +673,43 @@ def test_phase_timings_are_consistent(ctx):
     c.close()
 
 
+def test_timing_of_the_write_kernel_alone(ctx):
+    """et_ctx_enable_timing(ET_TIMING_DECODE_BODY): only the decode's write kernel carries its pair of events (what bench.py's
+    timed regions use: a dispatch with events costs queue time on either side of it).  The decode's timings then hold
+    body_ms, the host's time and the path flags, everything else 0; results are what they are with timing on or off; and
+    switching back gives the full set again."""
+    import torch
+
+    import entreepy_amd as E
+
+    c = E.Context(0)
+    c.use_torch_stream()
+    data = corpus.text_like(5_000_000, 21)
+    text = torch.from_numpy(data).cuda()
+    enc = torch.zeros(E.encode_bound(data.size) + 64, dtype=torch.uint8, device="cuda")
+    dec = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+    c.enable_timing(True)
+    m = c.encode_device(text, enc)
+    k = c.decode_device(enc[4:m], dec)
+    full = c.timings("decode")
+    image = enc[:m].clone()
+    c.enable_timing(c.TIMING_DECODE_BODY)
+    for _ in range(3):
+        dec.zero_()
+        m2 = c.encode_device(text, enc)
+        k = c.decode_device(enc[4:m2], dec)
+        td = c.timings("decode")
+        assert m2 == m and torch.equal(enc[:m], image) and k == data.size and torch.equal(dec[:k], text)
+        assert 0.0 < td["body_ms"] < 5 * full["body_ms"] + 1.0 and td["tree_walk_sync"] and td["chained_write"]
+        assert td["sync_ms"] == 0.0 and td["sync_first_ms"] == 0.0 and td["total_ms"] == 0.0 and td["scan_ms"] == 0.0
+    c.enable_timing(True)
+    m3 = c.encode_device(text, enc)
+    k = c.decode_device(enc[4:m3], dec)
+    te, td = c.timings("encode"), c.timings("decode")
+    assert te["hist_ms"] > 0 and td["sync_ms"] > 0 and td["body_ms"] > 0 and abs(td["sync_ms"] + td["body_ms"] - td["total_ms"]) < 0.02 * td["total_ms"] + 1e-3
+    c.close()
+
+
 def test_header_and_zero_bit_tiles_share_the_seam_word(ctx):
     """All 256 byte values occur, so the reference drops the most frequent one (quirk Q1: code
     length 0) -- and the text STARTS with 6 MiB of it: more than 1024 tiles (a whole scan group and
