@@ -2703,7 +2703,7 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     if (chain) {  // every block, one launch, no side lane, no ticket; `tb` is not looked at
         // 8 wavefronts per workgroup share the tables (17 KiB) beside their 4 KiB stages: 3 workgroups = 24 wavefronts per CU
-        constexpr int WAVES = 8;
+        constexpr int WAVES = 8;  // (12 x 2 per CU the same; 16 x 2 with 3.8 KiB stages, 32 wavefronts per CU, the same too: 0.441-0.445 ms; 4 x 4 or 16 x 1: 0.56)
         const size_t smem_wave = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + WAVES * WV_STAGE_ALLOC;
         const uint32_t n_units = (n_blocks * 4 + WAVES - 1) / WAVES;
         ET_LAUNCH_TIMED(k_dec_write_wave<WAVES>, dim3(decode_grid(k_dec_write_wave<WAVES>, smem_wave, n_units, true, 64 * WAVES)), dim3(64 * WAVES), smem_wave, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, void_flags, n_subs, chain_max_len);
