@@ -504,6 +504,12 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
         const bool interior = static_cast<uint64_t>(t) * tile_bytes >= lo && static_cast<uint64_t>(t + 1) * tile_bytes <= hi;
 
         Chunk cur = load_chunk_in_tile<ET_NT_LOAD_K4>(base, t0, lo, hi, interior);
+        // (`cur` is THERE when the loop is entered, and `nxt` is taken at a point of its own further down: left to the compiler,
+        // the round's first use of `cur` waited with vmcnt(0) -- loads come back in order, the first round's `cur` may still be
+        // on its way at the loop's head, so every round waited for the `nxt` it had only just asked for: no prefetch at all, a
+        // full memory latency per round)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(cur.w[k]));
         for (uint32_t r = 0; r < rounds_per_tile; ++r) {
             Chunk nxt;
             nxt.valid = 0;
@@ -603,6 +609,10 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
             if (fill) atomicOr(reinterpret_cast<uint32_t *>(ring_bytes + wbyte), part);
             run += round_total;
             __syncthreads();
+            // the next round's chunk is taken HERE, in front of this round's stores: loads and stores share the in-order vmcnt,
+            // and behind the stores the wait for the chunk would be a wait for them as well
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(nxt.w[k]));
             flush_words<RING_WORDS>(f, flushed, run >> 5);
             flushed = run >> 5;
             cur = nxt;
