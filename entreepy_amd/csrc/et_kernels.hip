@@ -2193,49 +2193,86 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
     const ChainWalk cw = {lds_tab | ((32u - CH_ROOT_BITS) << 24), lds_tab, max_len >= 32};
     __syncthreads();  // tables staged
     {
-        for (uint32_t u = blockIdx.x * WAVES + wv; u < n_blocks * 4; u += gridDim.x * WAVES) {
-            const uint64_t b = u >> 2;
+        // What a quarter needs from memory -- its block's output offset, the four quarters' state words, its nine stream words
+        // -- is asked for one quarter AHEAD and taken in front of the quarter's own output stores (loads and stores share the
+        // in-order vmcnt: behind the stores, a wait for the words is a wait for the stores as well).  The asm statements pin
+        // where the loads have to be back; without them the first use waits with vmcnt(0) for whatever was asked for last.
+        const uint32_t stride = gridDim.x * WAVES, n_units = n_blocks * 4;
+        uint64_t n_o0 = 0;
+        uint32_t n_stq[4] = {0, 0, 0, 0}, n_W[RW_WORDS];
+        bool n_edge = false;
+#define WV_FETCH(u_)                                                                                              \
+    {                                                                                                             \
+        const uint64_t b_ = (u_) >> 2;                                                                            \
+        const uint32_t quarter_ = (u_) & 3u;                                                                      \
+        n_o0 = blk_off[b_];                                                                                       \
+        n_edge = block_limit(n_bytes, b_) != 0xffffffffu;                                                         \
+        _Pragma("unroll") for (uint32_t q = 0; q < 4; ++q) {                                                      \
+            const uint64_t sg = b_ * BLOCK + q * 64 + lane;                                                       \
+            n_stq[q] = sg < n_subs ? sub_state[sg] : 0u;                                                          \
+        }                                                                                                         \
+        const uint64_t sub_g_ = b_ * BLOCK + quarter_ * 64 + lane;                                                \
+        if (sub_g_ < n_subs) {                                                                                    \
+            if (n_edge) {                                                                                         \
+                _Pragma("unroll") for (int j = 0; j < RW_WORDS; ++j)                                              \
+                    n_W[j] = j < 4 ? 0u : __builtin_bswap32(load_be32_guarded(words, sub_g_ * (SUB_BITS / 32) - 4 + j, n_bytes)); \
+            } else { /* (as they lie in memory: swapped when they are taken) */                                   \
+                const uint32_t *src_ = words + sub_g_ * (SUB_BITS / 32) - 4;                                      \
+                _Pragma("unroll") for (int j = 0; j < RW_WORDS; ++j) n_W[j] = j < 4 ? 0u : src_[j];               \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < RW_WORDS; ++j) n_W[j] = 0;                                      \
+        }                                                                                                         \
+    }
+        uint64_t o0 = 0;
+        uint32_t stq[4], W[RW_WORDS];
+        bool edge = false;
+#define WV_TAKE()                                                                     \
+    {                                                                                 \
+        o0 = n_o0;                                                                    \
+        edge = n_edge;                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                               \
+            stq[q] = n_stq[q];                                                        \
+            asm volatile("" : "+v"(stq[q]));                                          \
+        }                                                                             \
+        _Pragma("unroll") for (int j = 0; j < RW_WORDS; ++j) {                        \
+            uint32_t w_ = n_W[j];                                                     \
+            asm volatile("" : "+v"(w_));                                              \
+            W[j] = __builtin_bswap32(w_);                                             \
+        }                                                                             \
+    }
+        uint32_t u = blockIdx.x * WAVES + wv;
+        if (u < n_units) {
+            WV_FETCH(u)
+            WV_TAKE()
+        }
+        for (; u < n_units; u += stride) {
+            const bool more = u + stride < n_units;
+            if (more) WV_FETCH(u + stride)
+            bool taken = !more;
             const uint32_t quarter = u & 3u;
-            const uint64_t o0 = blk_off[b];
-            if (o0 >= n_symbols) continue;  // pad bits decoded past the declared length
-            const bool edge = block_limit(n_bytes, b) != 0xffffffffu;
             // the four quarters' counts (the same lane of each): where this one's output begins
             uint32_t before = 0, st = 0;
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
-                const uint64_t sg = b * BLOCK + q * 64 + lane;
-                const uint32_t v = sg < n_subs ? sub_state[sg] : 0u;
-                if (q == quarter) st = v;
-                if (q < quarter) before += v >> 16;
+                if (q == quarter) st = stq[q];
+                if (q < quarter) before += stq[q] >> 16;
             }
             before = wave_sum(before);
-            const uint64_t sub_g = b * BLOCK + quarter * 64 + lane;
             const uint32_t start = st & 31u;  // (a start is < 32 in a settled state; masked so that nothing else can reach the walk)
             const uint32_t count = st >> 16;
             const uint32_t inc = wave_inclusive_scan(count);
             const uint32_t wave_total = __builtin_amdgcn_readlane(inc, 63), my_off = inc - count;
             const uint64_t ow = o0 + before;  // the wavefront's first symbol
-            if (ow >= n_symbols || wave_total == 0) continue;
+            const bool nothing = o0 >= n_symbols || ow >= n_symbols || wave_total == 0;  // (pad bits decoded past the declared length)
             uint64_t o1 = ow + wave_total;
             if (o1 > n_symbols) o1 = n_symbols;
-            const uint32_t n_out = static_cast<uint32_t>(o1 - ow);
+            const uint32_t n_out = nothing ? 0u : static_cast<uint32_t>(o1 - ow);
             const uint32_t phase = static_cast<uint32_t>(ow & 15);  // stage offset of the first symbol
-            const uint32_t span = phase + n_out;
+            const uint32_t span = nothing ? 0u : phase + n_out;
             uint8_t *out_base = out + (ow - phase);
-            uint32_t W[RW_WORDS];
-            if (sub_g < n_subs) {
-                if (edge) {
-                    W[0] = W[1] = W[2] = W[3] = 0;
-#pragma unroll
-                    for (int j = 4; j < RW_WORDS; ++j) W[j] = load_be32_guarded(words, sub_g * (SUB_BITS / 32) - 4 + j, n_bytes);
-                } else {
-                    load_window<false>(W, words, sub_g);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < RW_WORDS; ++j) W[j] = 0;
-            }
-            const bool one_window = phase + wave_total <= WV_STAGE && n_out == wave_total && !edge;
+            const bool this_edge = edge;
+            const bool one_window = phase + wave_total <= WV_STAGE && n_out == wave_total && !this_edge;
             const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
             for (uint32_t win = 0; win < span; win += WV_STAGE) {
                 const uint32_t win_hi = min(win + WV_STAGE, span);
@@ -2245,6 +2282,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
                     walk_write_chain<2>(cw, smem8, W, start, my_lo, win, win_hi, stage_off);
                 }
                 // (the wavefront's own LDS stores, then its own loads: in order, no barrier)
+                if (!taken && win + WV_STAGE >= span) {  // the last window's walk is done: W and the state words are free
+                    WV_TAKE()
+                    taken = true;
+                }
                 const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
                 for (uint32_t g = win + lane * 16; g < win_hi; g += 64 * 16) {
                     if (g >= lo_valid && g + 16 <= win_hi) {
@@ -2261,7 +2302,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
                     if (lane < 32 && partial && pos >= lo_valid && pos < win_hi) out_base[pos] = stage[pos - win];
                 }
             }
+            if (!taken) WV_TAKE()
         }
+#undef WV_TAKE
+#undef WV_FETCH
     }
 }
 
