@@ -235,8 +235,8 @@ __device__ __forceinline__ void tw_lanes(uint32_t (&W)[TW_LANES][TW_WORDS], cons
 
 // What the block before block b published -- bit 31 | the node it ends in -- or 0 when that is `guess`, the node b's first lane
 // started from (0 also when nothing shows up within TW_PUB_POLLS looks).  Wavefront-uniform.
-__device__ __forceinline__ uint32_t tw_seen_before(const uint32_t *__restrict__ blk_pub, uint32_t b, uint32_t guess, uint32_t lane_id) {
-    uint32_t seen = 0;
+__device__ __forceinline__ uint32_t tw_seen_before(const uint32_t *__restrict__ blk_pub, uint32_t b, uint32_t guess, uint32_t lane_id, uint32_t seen = 0) {
+    // (`seen`: what an earlier look found -- asked for at the top of the trip, a walk ago, so that nobody waits for it here)
     if (lane_id == 0) {
         for (uint32_t poll = 0; poll < TW_PUB_POLLS && !(seen & 0x80000000u); ++poll) {
             seen = __hip_atomic_load(blk_pub + (b - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -300,6 +300,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ET_TW_WAVE
             break;
         }
         {
+        uint32_t early = 0;  // the word the pending block's predecessor published: asked for now, looked at behind this block's walk
+        if (blk_pub && !worklist && forced == 0xffffffffu && pend_b != 0xffffffffu && lane_id == 0)
+            early = __hip_atomic_load(blk_pub + (pend_b - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // wavefront-uniform: every word of the block, its run-in and the word after it is a whole word of the stream
         const long long bw0 = static_cast<long long>(b) * 2048 - TW_RUN;
         const bool edge = bw0 < 0 || static_cast<uint64_t>(bw0 + 2048 + TW_RUN + 1) > n_words_full;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ET_TW_WAVE
         if (blk_pub && !worklist && forced == 0xffffffffu) {
             if (lane_id == 63) __hip_atomic_store(blk_pub + b, 0x80000000u | r[1].s_out(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (pend_b != 0xffffffffu) {  // the block of the trip before: does it begin where the block before IT ends?
-                const uint32_t seen = tw_seen_before(blk_pub, pend_b, pend_start, lane_id);
+                const uint32_t seen = tw_seen_before(blk_pub, pend_b, pend_start, lane_id, early);
                 if (seen & 0x80000000u) {  // (never seen: the block keeps its guess, the verification decides)
                     again_b = pend_b;
                     again_row = seen & 0x7fffffffu;
