@@ -283,7 +283,9 @@ __global__ __launch_bounds__(BLOCK) void k_hist_reduce(const unsigned long long 
 // ET_HEADER_BOUND bytes are enough, whatever the codes are.
 __global__ __launch_bounds__(1024) void k_header_to_host(const uint8_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ host_dst,
                                                          unsigned long long *__restrict__ host_done, unsigned long long epoch) {
-    const uint32_t bound = header_bound(src[0]);
+    // (the most a dictionary can take, not what THIS one takes: reading src[0] first to know is a memory round trip in front of
+    // the copy -- 1544 bytes at most either way)
+    const uint32_t bound = header_bound(255);
     if (bound < n) n = bound;
     for (uint32_t w = threadIdx.x; w * 4 < n; w += 1024) {
         uint32_t v = 0;
@@ -321,7 +323,16 @@ __global__ __launch_bounds__(BLOCK) void k_tile_bits(const uint32_t *__restrict_
                                                      unsigned long long epoch) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0) {
-        for (uint32_t i = threadIdx.x; i < copy_words; i += BLOCK) dev_dst[i] = host_src[i];
+        // (all of a thread's loads first, then its stores: the source is HOST memory, ~2 us a round trip, and a plain copy loop
+        // waits for each word before it asks for the next -- up to 8 round trips in a row for the ~1900 words of a block)
+        for (uint32_t i0 = threadIdx.x; i0 < copy_words; i0 += 8 * BLOCK) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = i0 + k * BLOCK < copy_words ? host_src[i0 + k * BLOCK] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + k * BLOCK < copy_words) dev_dst[i0 + k * BLOCK] = v[k];
+        }
         __syncthreads();  // (every thread's loads have returned: the host may fill the block again once it sees `epoch`)
         if (threadIdx.x == 0) __hip_atomic_store(host_taken, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
