@@ -596,10 +596,12 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
                     }
                 }
                 if (!__any(wide2)) {
-                    // that lane appends that quad as its two pairs, looked up again; everybody else's quads go in whole
+                    // a quad POSITION in which some lane's quad is wide goes in as its two pairs, looked up again, for every lane of the
+                    // wavefront (the same bits either way); the other positions go in whole.  (Decided per lane, a wavefront with one
+                    // wide quad ran BOTH branches at all four positions: 12 appends and 16 lookups a round on a long-tailed alphabet.)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (qlen[q] <= 32) {
+                        if (__builtin_amdgcn_ballot_w64(qlen[q] > 32) == 0) {
                             ET_APPEND(qcode[q], qlen[q]);
                         } else {
                             const uint2 e0 = ET_ENTRY(4 * q), e1 = ET_ENTRY(4 * q + 1), e2 = ET_ENTRY(4 * q + 2), e3 = ET_ENTRY(4 * q + 3);
