@@ -1123,3 +1123,40 @@ def test_fallback_range_sync_is_what_a_sparse_dictionary_runs(ctx):
         pieces.append(buf[:m].cpu().numpy())
         c.close()
     assert np.concatenate(pieces)[:n].tobytes() == text.tobytes()
+
+
+def test_write_by_quarters_windows_ragged_ends_and_clamps(ctx):
+    """k_dec_write_wave: a wavefront owns a quarter of an 8 KiB block (64 subsequences) and a 4 KiB stage.  Streams whose
+    quarters decode to MORE than a stage holds (a 1-bit code: up to 16 K symbols per quarter -> several windows per
+    quarter), streams that end inside every quarter of their last block and inside a quarter's first / last subsequence,
+    declared lengths that cut the output inside a quarter, at a quarter's edge and at a 16-byte chunk's edge -- all against
+    the oracle's intended decoder; and output buffers at every 16-byte phase."""
+    import torch
+
+    O = _oracle()
+    rng = np.random.default_rng(2024)
+    # 1-bit code for one symbol, a tail of others: ~7 symbols per byte of stream
+    for p_hot, n in ((0.995, 3_000_000), (0.9, 1_500_000), (0.6, 800_000)):
+        base = np.where(rng.random(n) < p_hot, 120, corpus.text_like(n, int(p_hot * 1000))).astype(np.uint8)
+        et = O.encode(base)
+        body = len(et) - 4
+        assert ctx.decode(et[4:]) == base.tobytes(), p_hot
+        # the stream cut inside every quarter of a late block, and around subsequence edges (what is left decodes as the oracle says)
+        for cut in (1, 31, 32, 33, 2047, 2048, 2049, 4096 + 5, 6144 - 1, 8192 - 32, 8192, 8192 + 1):
+            if cut + 64 < body:
+                piece = et[4 : len(et) - cut]
+                assert ctx.decode(piece) == O.decode(piece), (p_hot, cut)
+    # declared lengths inside / at the edge of quarters and 16-byte chunks
+    text = corpus.text_like(700_000, 5)
+    et = bytearray(O.encode(text))
+    comp = torch.frombuffer(bytearray(et[4:]), dtype=torch.uint8).cuda()
+    full = O.decode(bytes(et[4:]))
+    for declared in (0, 1, 15, 16, 17, 3493, 3500, 4096, 4097, 13970, 13972 * 3 + 7, len(full) - 1, len(full)):
+        hdr = bytearray(et[4:])
+        hdr[1:5] = int(declared).to_bytes(4, "big")
+        want = O.decode(bytes(hdr))
+        assert ctx.decode(bytes(hdr)) == want, declared
+    # the output buffer at every phase of a 16-byte chunk is refused or right: the C ABI asks for 16-byte alignment
+    out = torch.empty(len(full) + 64, dtype=torch.uint8, device="cuda")
+    m = ctx.decode_device(comp, out)
+    assert m == len(full) and out[:m].cpu().numpy().tobytes() == full
