@@ -90,13 +90,160 @@ def cpu_baseline_parallel(sample_u8, what, threads, budget_s=8.0):
     }
 
 
-def load_pmc_traffic(kernel):
-    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/pmc_latest.json), or None."""
+def load_pmc_traffic(kernel, bytes_per_gpu):
+    """(HBM bytes per launch, where the figure comes from) from the committed rocprofv3 --pmc passes
+    (profiles/pmc_latest.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes of this same command on another box) -- NOT
+    measured by the run that prints the line -- or (None, why) when there are none or they were taken at another size."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            d = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/pmc_latest.json"
+    meta = d.get("_meta", {})
+    if meta.get("bytes_per_gpu", 1 << 30) != bytes_per_gpu:
+        return None, f"profiles/pmc_latest.json was collected at {meta.get('bytes_per_gpu', 1 << 30)} B per GPU, this run has {bytes_per_gpu}"
+    v = d.get(kernel, {}).get("hbm_bytes_per_launch")
+    return v, f"profiles/pmc_latest.json (tag {meta.get('tag', 'r03')}; rocprofv3 --pmc passes of this command, not this run)"
+
+
+def fail(msg):
+    """A failed check ends the run without a line (not an assert: python -O strips those)."""
+    sys.stderr.write(f"bench.py: {msg}\n")
+    sys.stderr.flush()
+    sys.exit(3)
+
+
+def uniform_bytes_torch(n, lo, hi, seed, dev):
+    """n uniform bytes in [lo, hi), generated on the device (BASELINE config 5: 16 GiB does not cross PCIe quickly)."""
+    import torch
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        out[s : s + m] = torch.randint(lo, hi, (m,), generator=g, device=dev, dtype=torch.int16).to(torch.uint8)
+    return out
+
+
+def measure_stream(torch, ctx, pipe, text, enc, dec, reps, lead, decode=True, verify=True):
+    """`lead` untimed + `reps` measured steps (encode to .et, cold decode back) of one HBM-resident stream, every phase carrying
+    HIP events (ctx.enable_timing(True)).  -> dict: n, packed_bytes, GB/s figures, phase_ms, which decode kernels ran.
+    decode=False: the stream has no inverse (all 256 byte values: the reference drops a symbol) -- encode only."""
+    n = text.numel()
+    ph = {"hist": 0.0, "enc_scan": 0.0, "enc_body": 0.0, "enc_total": 0.0, "dec_sync": 0.0, "dec_sync_first": 0.0, "dec_scan": 0.0, "dec_body": 0.0, "dec_total": 0.0}
+    m = n
+    td = None
+    # 1. the step as a caller pays it: no events, nothing read back between steps (host clock over `reps` steps)
+    torch.cuda.synchronize()
+    ctx.enable_timing(False)
+    for i in range(reps + lead):
+        if i == lead:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        r = pipe.encode_shard(text, enc, timings=False)
+        if decode:
+            m = pipe.decode_shard(enc, r, dec)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    # 2. the same steps with every phase carrying HIP events, read back after every step -> phase_ms
+    ctx.enable_timing(True)
+    for i in range(reps + 4):
+        r = pipe.encode_shard(text, enc, timings=False)
+        if decode:
+            m = pipe.decode_shard(enc, r, dec)
+        te = pipe.encode_timings()
+        if decode:
+            td = ctx.timings("decode")
+        if i >= 4:
+            for k in ("hist", "enc_scan", "enc_body", "enc_total"):
+                ph[k] += te[k]
+            if decode:
+                ph["dec_sync"] += td["sync_ms"]
+                ph["dec_sync_first"] += td["sync_first_ms"]
+                ph["dec_scan"] += td["scan_ms"]
+                ph["dec_body"] += td["body_ms"]
+                ph["dec_total"] += td["total_ms"]
+    torch.cuda.synchronize()
+    ok = None
+    if verify and decode:
+        ok = bool(m == n and torch.equal(dec[:n], text))
+        if not ok:
+            fail("round trip of an extra workload is not the identity")
+    cb = ctx.last_codebook()
+    p = {k: v / reps for k, v in ph.items()}
+    packed = r["body_bytes"]
+    out = {
+        "bytes": n, "packed_bytes": packed, "symbols": int(cb.raw.n_coded), "code_lengths": [int(cb.raw.min_length), int(cb.raw.max_length)],
+        "steps": reps, "lead_steps": lead,
+        "ms_per_step": round(wall, 4),  # host clock over `steps` uninstrumented steps behind `lead_steps` untimed ones
+        ("round_trip_GBps" if decode else "encode_only_GBps"): round(n / (wall * 1e-3) / 1e9, 2),  # n / ms_per_step
+        "encode_GBps": round(n / (p["enc_total"] * 1e-3) / 1e9, 2),
+        "encode_hbm_frac": round((2 * n + packed) / ((p["hist"] + p["enc_scan"] + p["enc_body"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "phase_ms": {k: round(v, 4) for k, v in p.items() if decode or not k.startswith("dec_")},
+    }
+    if decode:
+        out["decode_GBps"] = round(n / (p["dec_total"] * 1e-3) / 1e9, 2)
+        out["decode_hbm_frac"] = round((n + packed) / (p["dec_total"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        out["kernels_only_round_trip_GBps"] = round(n / ((p["enc_total"] + p["dec_total"]) * 1e-3) / 1e9, 2)  # n / (enc_total + dec_total): begin of K1 .. end of K4 plus begin of D1 .. end of D3, instrumented steps
+        out["decode_path"] = ("exhaustive maps (k_dec_maps_reg / k_dec_compose / k_dec_chain / k_dec_resolve_reg)" if td["exhaustive_sync"]
+                              else ("k_tw_sync" if td["tree_walk_sync"] else "k_dec_sync_reg2")) + " + " + ("k_dec_write_wave" if td["chained_write"] else "k_dec_write_reg")
+        out["verified"] = ok
+    return out
+
+
+EXTRA_WORKLOADS = ("enwik-like", "text-100M", "text-5M", "uniform255-4G", "uniform256-16G")
+
+
+def run_extra_workload(name, torch, E, corpus, ctx, pipe, dev, n_headline, verify=True, reps=None):
+    """One of BASELINE.json's other configurations (or the enwik-like stream) at N = 1, beside the headline: -> dict."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    if name == "enwik-like":
+        n = n_headline
+        text = corpus.enwik_like_torch(n, 0x5EED0009, dev)
+        what = f"enwik-like: {n} B, 206 symbols (96 Zipf-like + 110 with probabilities 2^-12 .. 2^-24), seed 0x5EED0009"
+        reps, lead, decode = reps or 10, 30, True
+    elif name == "text-100M":  # BASELINE configs[2] (enwik8's size; the corpus does not exist offline)
+        n = 100_000_000
+        real = corpus.from_env("ET_CORPUS_ENWIK8", n)
+        text = torch.from_numpy(real).to(dev) if real is not None else corpus.text_like_torch(n, 0x5EED0003, dev)
+        n = text.numel()
+        what = f"text-100M: {n} B, " + ("enwik8 ($ET_CORPUS_ENWIK8)" if real is not None else "order-0 samples of Midsummer's byte distribution, seed 0x5EED0003") + " (BASELINE configs[2])"
+        reps, lead, decode = reps or 40, 60, True
+    elif name == "text-5M":  # BASELINE configs[1] (the Complete Works' size)
+        n = 5_458_199
+        real = corpus.from_env("ET_CORPUS_SHAKESPEARE")
+        host = real if real is not None else corpus.tiled_midsummer(n)
+        text = torch.from_numpy(host).to(dev)
+        n = text.numel()
+        what = f"text-5M: {n} B, " + ("$ET_CORPUS_SHAKESPEARE" if real is not None else "a_midsummer_nights_dream.txt tiled") + " (BASELINE configs[1])"
+        reps, lead, decode = reps or 100, 100, True
+    elif name == "uniform255-4G":  # BASELINE configs[4]'s decode half: the largest lossless stream of the format
+        n = (4 << 30) - (1 << 20)
+        if free < 3 * n + (3 << 30):
+            return {"skipped": f"needs ~{(3 * n) >> 30} GiB of free HBM, {free >> 30} GiB are free"}
+        text = uniform_bytes_torch(n, 1, 256, 0x5EED0055, dev)
+        what = (f"uniform255-4G: {n} B uniform over byte values 1..255, seed 0x5EED0055 (BASELINE configs[4] where the format is lossless: 255 symbols, "
+                f"just under 4 GiB -- the reference drops one of 256 symbols, Q1, and wraps the length at 4 GiB, Q4); codes of 7-8 bits do not self-synchronise")
+        reps, lead, decode = reps or 5, 3, True
+    elif name == "uniform256-16G":  # BASELINE configs[4], encode
+        n = 16 << 30
+        if free < 2 * n + (4 << 30):
+            return {"skipped": f"needs ~{(2 * n) >> 30} GiB of free HBM, {free >> 30} GiB are free"}
+        text = uniform_bytes_torch(n, 0, 256, 0x5EED0005, dev)
+        what = (f"uniform256-16G: {n} B uniform over all 256 byte values, seed 0x5EED0005 (BASELINE configs[4]), encode only: with 256 distinct "
+                f"values the reference's encoder drops a symbol (Q1) and the stream has no inverse")
+        reps, lead, decode = reps or 5, 2, False
+    else:
+        return {"error": f"unknown workload {name}"}
+    n = text.numel()
+    ctx.reserve(n)
+    enc = torch.zeros(E.encode_bound(n) + 64, dtype=torch.uint8, device=dev)
+    dec = torch.empty(n + 64, dtype=torch.uint8, device=dev) if decode else None
+    out = {"workload": what}
+    out.update(measure_stream(torch, ctx, pipe, text, enc, dec, reps, lead, decode, verify))
+    return out
 
 
 def main():
@@ -113,7 +260,10 @@ def main():
     ap.add_argument("--bytes", type=int, default=int(os.environ.get("ET_BENCH_BYTES", 1 << 30)), help="text bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the chunk-parallel CPU baseline (0: min(cores, 16))")
-    ap.add_argument("--no-second-workload", action="store_true", help="skip the enwik-like stream measured after the headline (N=1)")
+    ap.add_argument("--no-second-workload", "--no-extra-workloads", dest="no_second_workload", action="store_true",
+                    help="skip the streams measured after the headline at N=1 (enwik-like and BASELINE's other configurations)")
+    ap.add_argument("--workloads", default=os.environ.get("ET_BENCH_WORKLOADS", ",".join(EXTRA_WORKLOADS)),
+                    help="which of them, comma-separated: " + ", ".join(EXTRA_WORKLOADS))
     ap.add_argument("--ref-value", type=float, default=None, help="the 1-GPU value (GB/s) a N > 1 line's scaling_efficiency is computed against")
     args = ap.parse_args()
 
@@ -138,6 +288,7 @@ def main():
     import torch.distributed as dist
 
     import entreepy_amd as E
+    from entreepy_amd import _native as N
     from entreepy_amd import sharded
     from tests import corpus
 
@@ -270,8 +421,9 @@ def main():
     for _ in range(2):
         step(False, True)
     torch.cuda.synchronize()
-    verify = os.environ.get("ET_BENCH_NO_VERIFY") != "1"  # (timing probes: builds whose kernels give wrong results on purpose)
-    assert not verify or (state["decoded"] == n and torch.equal(dec[:n], text)), "round trip is not the identity"
+    verify = os.environ.get("ET_BENCH_NO_VERIFY") != "1"  # (timing probes: builds whose kernels give wrong results on purpose; the line then says "verified": false and carries value_unverified instead of value)
+    if verify and not (state["decoded"] == n and torch.equal(dec[:n], text)):
+        fail("round trip is not the identity")
     for _ in range(args.warmup):
         step(False, True)
     elapsed_cold = timed_region()
@@ -294,7 +446,8 @@ def main():
     body_ms_timed = phases["dec_body"] / args.steps  # the write kernel's own events, every step of the timed region
     timing_mode(all_phases=True)  # (the second workload below reports its phases)
     m_bytes = state["layout"]["body_bytes"]  # packed body bytes of this rank's shard (worked out here, off the timed path)
-    assert not verify or (state["decoded"] == n and torch.equal(dec[:n], text)), "round trip of the last timed step is not the identity"
+    if verify and not (state["decoded"] == n and torch.equal(dec[:n], text)):
+        fail("round trip of the last timed step is not the identity")
 
     # N > 1: the bit-offset-adjusted concatenation of the shards into ONE image on rank 0 (seam merge + owned
     # words over xGMI), timed on its own after the headline region -- it is not part of `value`.
@@ -317,42 +470,24 @@ def main():
         concat_ms = float(tmax.item())
         seam_ms = pipe.lib_group.info()["seam_ms"] if pipe.lib_group is not None else None
 
-    # N = 1: a second stream, enwik-like (206 symbols, code lengths up to 24: the long codes the text stream never
-    # shows), same step, a few repetitions -- reported beside the headline, never instead of it.
-    second = None
+    # N = 1: the other streams -- enwik-like (206 symbols, code lengths up to 24: the long codes the text stream never shows) and
+    # BASELINE.json's other configurations (5.4 MB and 10^8 B of text, 4 GiB of 255 uniform byte values through the exhaustive
+    # decode, 16 GiB of 256 for the encode) -- same step, a few repetitions each, reported beside the headline, never instead of it.
+    extras = None
     if world == 1 and not force_group and not args.no_second_workload:
-        try:  # (beside the headline: whatever goes wrong here is reported in its place and does not cost the line)
-            del text
+        extras = {}
+        del text, enc, dec
+        text = None
+        for name in [w for w in args.workloads.split(",") if w]:
             torch.cuda.empty_cache()
-            text2 = corpus.enwik_like_torch(n, 0x5EED0009, dev)
-            ph2 = {"hist": 0.0, "enc_scan": 0.0, "enc_body": 0.0, "enc_total": 0.0, "dec_sync_first": 0.0, "dec_body": 0.0, "dec_total": 0.0}
-            reps, lead = 10, 30  # (30 untimed steps first: the GPU's clocks after the generator's idle stretch, see above)
-            for i in range(reps + lead):
-                r2 = pipe.encode_shard(text2, enc, timings=False)
-                m2 = pipe.decode_shard(enc, r2, dec)
-                te, td = pipe.encode_timings(), ctx.timings("decode")
-                if i >= lead:
-                    for k in ("hist", "enc_scan", "enc_body", "enc_total"):
-                        ph2[k] += te[k]
-                    ph2["dec_sync_first"] += td["sync_first_ms"]
-                    ph2["dec_body"] += td["body_ms"]
-                    ph2["dec_total"] += td["total_ms"]
-            torch.cuda.synchronize()
-            assert m2 == n and torch.equal(dec[:n], text2), "enwik-like round trip is not the identity"
-            cb2 = ctx.last_codebook()
-            p2 = {k: v / reps for k, v in ph2.items()}
-            second = {
-                "workload": f"enwik-like: {n} B, 206 symbols (96 Zipf-like + 110 with probabilities 2^-12 .. 2^-24), seed 0x5EED0009",
-                "symbols": int(cb2.raw.n_coded), "code_lengths": [int(cb2.raw.min_length), int(cb2.raw.max_length)],
-                "packed_bytes": r2["body_bytes"],
-                "encode_GBps": round(n / (p2["enc_total"] * 1e-3) / 1e9, 2), "decode_GBps": round(n / (p2["dec_total"] * 1e-3) / 1e9, 2),
-                "round_trip_GBps": round(n / ((p2["enc_total"] + p2["dec_total"]) * 1e-3) / 1e9, 2),
-                "phase_ms": {k: round(v, 4) for k, v in p2.items()},
-            }
-            text = text2
-        except Exception as e:  # noqa: BLE001
-            second = {"error": repr(e)}
-            torch.cuda.synchronize()
+            try:  # (beside the headline: whatever goes wrong here is reported in its place and does not cost the line)
+                extras[name] = run_extra_workload(name, torch, E, corpus, ctx, pipe, dev, n, verify)
+            except SystemExit:
+                raise
+            except Exception as e:  # noqa: BLE001
+                extras[name] = {"error": repr(e)}
+                torch.cuda.synchronize()
+        torch.cuda.empty_cache()
 
     if rank == 0:
         K = args.steps
@@ -372,12 +507,13 @@ def main():
         if in_timed_region:  # (the kernel that carries its events through the timed region; any other: the instrumented steps' figure)
             d_ms = body_ms_timed
         achieved = d_bytes / (d_ms * 1e-3) / 1e9
+        traffic, traffic_source = load_pmc_traffic(dominant.split("<")[0], n)
         # whole encode on the GPU's clock, begin of K1 to end of K4 (enc_scan = everything between the
         # two: histogram reduce, the host's code construction, tile scan, uploads)
         enc_kernel_ms = ms["hist"] + ms["enc_scan"] + ms["enc_body"]
         out = {
             "metric": "GB/s encode+decode on 1 GiB text at 1/2/4/8 MI355X; % of HBM read peak",
-            "value": round(world * n / elapsed * K / 1e9, 3),
+            ("value" if verify else "value_unverified"): round(world * n / elapsed * K / 1e9, 3),
             "unit": "GB/s",
             "n_gpus": world,
             "steps": K,
@@ -391,6 +527,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic" if real_sample is None else "enwik9 ($ET_CORPUS_ENWIK9)",
+            "verified": bool(verify),  # both round trips (before the warm-up, after the last timed step) compared with the input on the device
+            "library": N.LIB_PATH,     # the shared object the step ran in ($ET_LIB_PATH swaps in another build)
             "config": {
                 "workload": workload_name + ", one step = encode to .et + decode back, HBM-resident",
                 "bytes_per_gpu": n,
@@ -411,7 +549,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
-                "traffic": load_pmc_traffic(dominant.split("<")[0]),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "ms_per_launch": round(d_ms, 4),
                 "algorithmic_bytes_per_launch": d_bytes,
                 "measured": ("HIP events carried by the dispatch, every step of the timed region" if in_timed_region
@@ -430,13 +569,13 @@ def main():
             if args.ref_value:
                 out["scaling_efficiency"] = round(out["value"] / (world * args.ref_value), 4)  # value(N) / (N x value(1)), value(1) = --ref-value
                 out["ref_value"] = args.ref_value
-        if second is not None:
-            out["workloads"] = {"enwik-like": second}
+        if extras is not None:
+            out["workloads"] = extras
         if world == 1 and not args.no_cpu_baseline:
             if real_sample is not None:
                 host_text = real_sample
             else:
-                text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev) if second is not None else text  # the headline stream again
+                text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev) if text is None else text  # the headline stream again
                 host_text = text[: min(n, 1 << 30)].cpu().numpy()
             what = "enwik9" if real_sample is not None else "text-1G"
             out["cpu_baseline"] = cpu_baseline(host_text[: 768 << 20], what)

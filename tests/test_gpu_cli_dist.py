@@ -411,7 +411,8 @@ def test_bench_line_has_the_contract_keys():
     import sys
 
     env = dict(os.environ, ET_BENCH_BYTES=str(32 << 20))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--cpu-threads", "4"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--cpu-threads", "4",
+                        "--workloads", "enwik-like,text-5M"],  # (the 4 GiB and 16 GiB streams of BASELINE config 5 are the default run's)
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -431,6 +432,12 @@ def test_bench_line_has_the_contract_keys():
     assert "phase_ms_measured" in d and all(d["phase_ms"][k] > 0 for k in ("hist", "enc_body", "dec_sync_first", "dec_body"))
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
     assert "error" not in d["workloads"]["enwik-like"] and d["workloads"]["enwik-like"]["round_trip_GBps"] > 0
+    t5 = d["workloads"]["text-5M"]
+    assert t5["bytes"] == 5_458_199 and t5["verified"] is True and t5["round_trip_GBps"] > 0 and "k_tw_sync" in t5["decode_path"]
+    # what the line does NOT measure itself says so: the PMC traffic is the committed passes' (and absent for a run of another size);
+    # whether the round trips were compared, and which build of the library ran
+    assert d["verified"] is True and d["library"].endswith("libentreepy_hip.so")
+    assert rf["traffic"] is None and "1073741824" in rf["traffic_source"]
     # the run as the contract words it (W warm-up steps, K timed) is in the line beside the steady-state figure
     assert d["value_cold"] > 0 and abs(d["value_cold"] - (32 << 20) / (d["ms_per_step_cold"] * 1e-3) / 1e9) < 0.01 * d["value_cold"]
     assert d["config"]["decode"].startswith("cold")

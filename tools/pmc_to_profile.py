@@ -17,7 +17,11 @@ for k, v in raw.items():
         e["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
     out[name] = e
-for path in (f"profiles/{tag}_pmc.json", "profiles/pmc_latest.json"):
+# what the figures belong to: bench.py's line carries them only for a run of the same size, and says where they come from
+bytes_per_gpu = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 30
+out["_meta"] = {"tag": tag, "bytes_per_gpu": bytes_per_gpu, "command": "rocprofv3 --pmc <pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-workload (tools/pmc_passes.sh)"}
+paths = (f"profiles/{tag}_pmc.json", "profiles/pmc_latest.json") if bytes_per_gpu == 1 << 30 else (f"profiles/{tag}_pmc.json",)
+for path in paths:
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 print("wrote", len(out), "kernels")
