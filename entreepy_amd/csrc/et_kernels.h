@@ -6,6 +6,17 @@
 
 #include "et_tables.h"
 
+// A value made "new" to the compiler at this point of the program (an empty asm statement with the value as an in/out
+// operand).  Three of round 3's gains hang on such pins: K4's and D3's prefetches (where the wait for a load that was asked
+// for a round / a unit ahead is placed) and D1's edge-block step limits (kept from being hoisted in front of every block).
+// None changes a result, so no parity test sees one go missing -- tests/test_isa_guard.py compiles the kernels to ISA and
+// checks what the pins hold in place, and builds them once more with -DET_GUARD_DROP_PINS to show that it would notice.
+#ifdef ET_GUARD_DROP_PINS
+#define ET_PIN(x_) ((void)0)
+#else
+#define ET_PIN(x_) asm volatile("" : "+v"(x_))
+#endif
+
 namespace et {
 
 constexpr int BLOCK = 256;                    // threads per workgroup: 4 wavefronts of 64

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
         // on its way at the loop's head, so every round waited for the `nxt` it had only just asked for: no prefetch at all, a
         // full memory latency per round)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(cur.w[k]));
+        for (int k = 0; k < 4; ++k) ET_PIN(cur.w[k]);
         for (uint32_t r = 0; r < rounds_per_tile; ++r) {
             Chunk nxt;
             nxt.valid = 0;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(BLOCK) void k_encode_tiles(const uint8_t *__restric
             // the next round's chunk is taken HERE, in front of this round's stores: loads and stores share the in-order vmcnt,
             // and behind the stores the wait for the chunk would be a wait for them as well
 #pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(nxt.w[k]));
+            for (int k = 0; k < 4; ++k) ET_PIN(nxt.w[k]);
             flush_words<RING_WORDS>(f, flushed, run >> 5);
             flushed = run >> 5;
             cur = nxt;
@@ -2246,11 +2246,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
         edge = n_edge;                                                                \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                               \
             stq[q] = n_stq[q];                                                        \
-            asm volatile("" : "+v"(stq[q]));                                          \
+            ET_PIN(stq[q]);                                                           \
         }                                                                             \
         _Pragma("unroll") for (int j = 0; j < RW_WORDS; ++j) {                        \
             uint32_t w_ = n_W[j];                                                     \
-            asm volatile("" : "+v"(w_));                                              \
+            ET_PIN(w_);                                                               \
             W[j] = __builtin_bswap32(w_);                                             \
         }                                                                             \
     }
@@ -2262,7 +2262,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
         for (; u < n_units; u += stride) {
             const bool more = u + stride < n_units;
             if (more) WV_FETCH(u + stride)
-            bool taken = !more;
             const uint32_t quarter = u & 3u;
             // the four quarters' counts (the same lane of each): where this one's output begins
             uint32_t before = 0, st = 0;
@@ -2287,35 +2286,48 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
             const bool this_edge = edge;
             const bool one_window = phase + wave_total <= WV_STAGE && n_out == wave_total && !this_edge;
             const uint32_t my_lo = phase + my_off, my_hi = my_lo + count;
-            for (uint32_t win = 0; win < span; win += WV_STAGE) {
-                const uint32_t win_hi = min(win + WV_STAGE, span);
-                if (one_window) {
-                    if (count) walk_write_chain<1>(cw, smem8, W, start, lds_stage + my_lo - 1u, 0, 0, 0);
-                } else if (my_lo < win_hi && my_hi > win) {
-                    walk_write_chain<2>(cw, smem8, W, start, my_lo, win, win_hi, stage_off);
-                }
-                // (the wavefront's own LDS stores, then its own loads: in order, no barrier)
-                if (!taken && win + WV_STAGE >= span) {  // the last window's walk is done: W and the state words are free
-                    WV_TAKE()
-                    taken = true;
-                }
-                const uint32_t lo_valid = max(win, phase);  // first stage position holding a symbol in this window
-                for (uint32_t g = win + lane * 16; g < win_hi; g += 64 * 16) {
-                    if (g >= lo_valid && g + 16 <= win_hi) {
-                        typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-                        // (non-temporal: plain stores cost this kernel nothing, but the NEXT encode's K4 6 % -- 0.392 against 0.370)
-                        __builtin_nontemporal_store(*reinterpret_cast<const u32x4_nt *>(stage + (g - win)), reinterpret_cast<u32x4_nt *>(out_base + g));
-                    }
-                }
-                // the two chunks the wavefront shares with its neighbours (or the window's ends): its own bytes only, one per lane
-                {
-                    const uint32_t head = lo_valid & ~15u, tail = win_hi & ~15u;
-                    const uint32_t pos = (lane < 16 ? head : tail) + (lane & 15u);
-                    const bool partial = lane < 16 ? (lo_valid & 15u) != 0 : (win_hi & 15u) != 0;  // (one chunk for both: its bytes are stored twice)
-                    if (lane < 32 && partial && pos >= lo_valid && pos < win_hi) out_base[pos] = stage[pos - win];
+            // A window: walk into the stage, then store the stage.  The NEXT unit's words are taken exactly once per unit, at one
+            // place in program order -- behind the unit's last walk (W is free) and in front of that window's stores (loads and
+            // stores share the in-order vmcnt).  (Round 3 took them inside the window loop, under `if (last window)`: the
+            // compiler's wait-count pass does not correlate that condition across the loop, saw loads that MIGHT still be
+            // pending at the unit loop's head and put `s_waitcnt vmcnt(0)` there -- in front of the next fetch, i.e. every unit
+            // waited for its own output stores to land before it asked for anything.)
+#define WV_WINDOW_WALK(win_, win_hi_)                                                                      \
+    if (one_window) {                                                                                      \
+        if (count) walk_write_chain<1>(cw, smem8, W, start, lds_stage + my_lo - 1u, 0, 0, 0);              \
+    } else if (my_lo < (win_hi_) && my_hi > (win_)) {                                                      \
+        walk_write_chain<2>(cw, smem8, W, start, my_lo, (win_), (win_hi_), stage_off);                     \
+    }
+// (the wavefront's own LDS stores, then its own loads: in order, no barrier)
+#define WV_WINDOW_STORE(win_, win_hi_)                                                                     \
+    {                                                                                                      \
+        const uint32_t lo_valid = max((win_), phase); /* first stage position holding a symbol in this window */ \
+        for (uint32_t g = (win_) + lane * 16; g < (win_hi_); g += 64 * 16) {                               \
+            if (g >= lo_valid && g + 16 <= (win_hi_)) {                                                    \
+                typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));                             \
+                /* (non-temporal: plain stores cost this kernel nothing, but the NEXT encode's K4 6 % -- 0.392 against 0.370) */ \
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4_nt *>(stage + (g - (win_))), reinterpret_cast<u32x4_nt *>(out_base + g)); \
+            }                                                                                              \
+        }                                                                                                  \
+        /* the two chunks the wavefront shares with its neighbours (or the window's ends): its own bytes only, one per lane */ \
+        const uint32_t head = lo_valid & ~15u, tail = (win_hi_) & ~15u;                                    \
+        const uint32_t pos = (lane < 16 ? head : tail) + (lane & 15u);                                     \
+        const bool partial = lane < 16 ? (lo_valid & 15u) != 0 : ((win_hi_) & 15u) != 0; /* (one chunk for both: its bytes are stored twice) */ \
+        if (lane < 32 && partial && pos >= lo_valid && pos < (win_hi_)) out_base[pos] = stage[pos - (win_)]; \
+    }
+            uint32_t win = 0;
+            if (span) {
+                for (;; win += WV_STAGE) {
+                    const uint32_t win_hi = min(win + WV_STAGE, span);
+                    WV_WINDOW_WALK(win, win_hi)
+                    if (win_hi == span) break;  // the last window: its stores come behind the take
+                    WV_WINDOW_STORE(win, win_hi)
                 }
             }
-            if (!taken) WV_TAKE()
+            WV_TAKE()
+            if (span) WV_WINDOW_STORE(win, span)
+#undef WV_WINDOW_STORE
+#undef WV_WINDOW_WALK
         }
 #undef WV_TAKE
 #undef WV_FETCH

@@ -383,7 +383,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ET_TW_WAVE
             if (edge) {
                 // (the limits are "new" to every trip: left loop-invariant, the edge walk's 128 step-limit compares are hoisted in
                 // front of the trip loop, where EVERY block pays for them -- 337 of a block's ~1360 VALU instructions)
-                asm volatile("" : "+v"(limit[0]), "+v"(limit[1]));
+                ET_PIN(limit[0]);
+                ET_PIN(limit[1]);
                 tw_lanes<true, true>(W, Rn, skip, limit, need, r, ck);
             } else {
                 tw_lanes<false, true>(W, Rn, skip, limit, need, r, ck);
