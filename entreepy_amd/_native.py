@@ -103,6 +103,7 @@ SIGNATURES = {
     "et_treewalk_table": (ctypes.c_int, [_cbp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "et_selftest_treewalk_table": (ctypes.c_int, [_vp, _cbp, ctypes.POINTER(ctypes.c_uint32)]),
     "et_chain_tables": (ctypes.c_int, [_cbp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), _vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
+    "et_row_code": (ctypes.c_int, [_cbp, ctypes.POINTER(ctypes.c_uint32)]),
     "et_encode_bound": (_sz, [_sz]),
     "et_encode_fd": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "et_decode_fd": (ctypes.c_int, [_vp, ctypes.c_int, _sz, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),

@@ -205,6 +205,7 @@ class Context:
         d["exhaustive_sync"] = bool(t.reserved & 1)
         d["tree_walk_sync"] = bool(t.reserved & 2)
         d["chained_write"] = bool(t.reserved & 4)
+        d["row_sync"] = bool(t.reserved & 8)
         return d
 
     def last_codebook(self):

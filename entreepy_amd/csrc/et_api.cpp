@@ -14,6 +14,7 @@
 
 #include "et_io.h"
 #include "et_kernels.h"
+#include "et_rowsync.h"
 #include "et_tables.h"
 #include "et_treewalk.h"
 
@@ -62,6 +63,7 @@ struct et_ctx {
     // decode workspaces
     DevBuf sub_state, blk_exit, blk_count, blk_off, lut, flag, worklist;  // flag: [0..3] sweep flags, [4] ticket, [8..] worklist counts  // lut: all decode tables, DEC_TABLES_BYTES
     DevBuf lane_maps, blk_maps, grp_maps, blk_in, grp_in;  // exhaustive synchronisation only
+    DevBuf row_scratch;                                    // the row walk's published words and ticket (et_rowsync.h)
     DevBuf tw_table, tw_tree, blk_start, blk_pub, chain_table;  // tree-walk synchronisation, chained write tables (et_treewalk.h)
     et::TwUpload *h_tw_tree[2] = {};                       // pinned, used in turn like h_lut_buf
     int tw_turn = 0;
@@ -390,7 +392,7 @@ extern "C" void et_ctx_destroy(et_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->tile_hist, &ctx->block_hist, &ctx->hist, &ctx->tile_bits, &ctx->tile_off, &ctx->enc_table, &ctx->group_sum,
                       &ctx->sub_state, &ctx->blk_exit, &ctx->blk_count, &ctx->blk_off, &ctx->lut, &ctx->flag,
-                      &ctx->worklist, &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in,
+                      &ctx->worklist, &ctx->lane_maps, &ctx->blk_maps, &ctx->grp_maps, &ctx->blk_in, &ctx->grp_in, &ctx->row_scratch,
                       &ctx->tw_table, &ctx->tw_tree, &ctx->blk_start, &ctx->blk_pub, &ctx->chain_table, &ctx->io_in, &ctx->io_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -981,6 +983,14 @@ extern "C" int et_chain_tables(const et_codebook *cb, uint64_t *table, size_t ca
     return ET_OK;
 }
 
+extern "C" int et_row_code(const et_codebook *cb, uint32_t *t) {
+    if (!cb || !t) return ET_ERR_ARG;
+    et::RowCode rc{};
+    if (!et::row_code_of(cb, &rc)) return ET_ERR_UNSUPPORTED;
+    *t = rc.t;
+    return ET_OK;
+}
+
 extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body, size_t body_bytes, uint32_t start_bit,
                                      uint64_t n_symbols, void *d_out, size_t cap, size_t *out_len) {
     if (!ctx || !cb || !out_len) return ET_ERR_ARG;
@@ -1029,7 +1039,12 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (et::tw_build_tree(cb, &h_up->tree, true) != ET_OK) h_up = nullptr;  // (bit patterns without a symbol become leaves that decode as byte 0)
     }
     const bool tw_sweeps = h_up && !exhaustive;
-    if (!tw_sweeps) ET_TRY(need_tables(true));
+    // Uniform-like bytes (complete codes of 7 and 8 bits, BASELINE's worst case): one pass by rows and columns (et_rowsync.h)
+    // instead of the exit maps for every start offset; the write then goes over the chained tables as for any full tree.
+    et::RowCode row_code{};
+    static const bool row_off = [] { const char *e = std::getenv("ET_NO_ROW_SYNC"); return e && e[0] == '1'; }();  // (A/B and the fallback's tests)
+    const bool row_sync = exhaustive && h_up && !row_off && et::row_code_of(cb, &row_code);
+    if (!tw_sweeps && !row_sync) ET_TRY(need_tables(true));
     const double t1 = now_ms();
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
@@ -1089,7 +1104,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         }
         tw_n_int = h_up->tree.n_int;
         n_chain = h_up->plan.n_entries;
-        const bool zero_here = !flags_zeroed && !exhaustive;
+        const bool zero_here = !flags_zeroed && (!exhaustive || row_sync);
         // (the kernel reads the tree and the plan from the pinned block itself: no upload in front of it)
         et::launch_tw_build(ctx->stream, h_up, static_cast<uint32_t>(et::tw_upload_bytes(h_up)), tw_n_int, tw_sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr, n_chain,
                             static_cast<uint64_t *>(ctx->chain_table.p), zero_here ? flag : nullptr, tw_sweeps ? static_cast<uint32_t *>(ctx->blk_pub.p) : nullptr, n_blocks);
@@ -1133,7 +1148,16 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         more_sweeps = !exhaustive && h_flags[2] != 0;
         if (!et::dec_state_final(h_flags[1], h_flags[2], n_blocks)) wrote = false;  // the speculative launch declined by the same rule
     }
-    if (exhaustive) {
+    if (exhaustive && row_sync) {
+        if (iters == 0) {
+            record(ctx, EV_DEC + 0);
+            record(ctx, EV_DEC + 5);
+        }
+        ET_TRY(ensure(ctx, ctx->row_scratch, et::row_sync_scratch_bytes(n_blocks)));
+        et::launch_row_sync(ctx->stream, words, n_bytes, first_bit, n_subs, row_code, ctx->row_scratch.p, flag + 3, sub_state, blk_exit, blk_count);
+        ET_HIP(hipGetLastError());
+        iters += 1;
+    } else if (exhaustive) {
         ET_TRY(need_tables(false));
         // The exhaustive kernels count with the older lookup tables, for which a bit pattern without a symbol is passed
         // over bit by bit; in the chained tables it is a leaf that decodes as byte 0.  The two agree on every stream of a
@@ -1177,6 +1201,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     if (exhaustive || more_sweeps) {
         ET_TRY(scan_and_total(false));
         ET_TRY(wait_report());
+        if (row_sync && h_flags[3] != 0) return fail(ctx, ET_ERR_HIP, "the row walk's chunks never saw the chunks before them");
     }
     const uint64_t decodable = static_cast<uint64_t>(h_flags[12]) | (static_cast<uint64_t>(h_flags[13]) << 32);
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
@@ -1187,7 +1212,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm_dec = et_timings{};
         ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
         ctx->tm_dec.sync_iters = iters;
-        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u);
+        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u);
         ctx->pend_dec = true;
         ctx->pend_dec_first = iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2);
         ctx->last_kind = 1;

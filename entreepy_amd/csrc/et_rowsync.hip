@@ -1,0 +1,333 @@
+// et_rowsync.hip -- one-pass synchronisation of 8-bit near-fixed-length codes (et_rowsync.h), gfx950 / wave64.
+//
+//   decode.zig:143-203 -> k_row_sync: where does the first codeword of every 256-bit subsequence begin, and how many begin in it?
+//
+// A lane owns a subsequence = 32 rows (bytes) x 8 columns (bit offsets).  It
+//   1. transposes its 32 bytes so that four rows sit in one register (24 v_perm),
+//   2. works out S[r], r = 0..7: bit j of S[r] says "the 7 bits at row j, column r are a 7-bit codeword" -- a byte-parallel add
+//      and mask per four rows, 7 VALU instructions per (four rows, column), no lookups,
+//   3. follows, for each of the 8 columns a walk can enter the subsequence in, the path to the subsequence's end: a path stays
+//      in its column until the next set bit of S[column] (v_ffbl), then moves one column to the left.  ALL lanes' paths visit the
+//      columns in the same order, so iteration t of the walk from column c works on the register S[(c - t) & 7] in every lane:
+//      no indexing.  Result: the lane's MAP (entry column -> exit column, a byte each: 8 bytes) and the codeword count per entry,
+//   4. composes maps: a map is 8 bytes of values 0..7, and v_perm_b32 IS the composition of two such maps -- a wavefront's
+//      inclusive scan of its 64 maps is 6 x (2 shuffles + 2 v_perm).
+// A workgroup takes chunks of ROW_CHUNK_BLOCKS 8 KiB blocks by ticket, keeps the lanes' prefix maps in LDS, publishes the
+// chunk's map (one 8-byte word: the map's bytes, the kind in two spare bits), looks back over the chunks before it --
+// 64 at a time, composing what they published -- until it meets one whose entry column is known, publishes its own, and then
+// every lane reads its start off its prefix map.  The stream is read once; nothing but the results leaves the chip.
+// (A ticket, not the block index, orders the chunks: a chunk only ever waits for chunks with smaller tickets, and those were
+// taken by workgroups that are running.)
+#include "et_rowsync.h"
+
+#include <hip/hip_runtime.h>
+
+namespace et {
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr uint32_t RS_CH = ROW_CHUNK_BLOCKS;
+constexpr uint32_t RS_WAVES = RS_CH * 4;        // wavefront-blocks per chunk
+constexpr uint32_t ID_LO = 0x03020100u, ID_HI = 0x07060504u;  // the identity map
+constexpr uint32_t RS_SPINS = 1u << 24;         // looks at a word that never comes before a chunk gives up (seconds)
+constexpr unsigned long long KIND_MAP = 1ull << 3, KIND_ENTRY = 2ull << 3;  // in byte 0 of a published word, above the column's 3 bits
+
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// byte `idx` (0..7) of the 8-byte map {lo, hi}
+__device__ __forceinline__ uint32_t map_at(uint32_t lo, uint32_t hi, uint32_t idx) { return perm(hi, lo, idx | 0x0c0c0c00u); }
+
+// stream word idx as it lies in memory, zero outside the stream
+__device__ __attribute__((noinline)) uint32_t rs_load_guarded(const uint32_t *__restrict__ words, uint64_t idx, uint64_t n_bytes) {
+    const uint64_t b0 = idx * 4;
+    if (b0 + 4 <= n_bytes) return words[idx];
+    uint32_t v = 0;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(words);
+    for (int k = 0; k < 4; ++k)
+        if (b0 + k < n_bytes) v |= static_cast<uint32_t>(bytes[b0 + k]) << (8 * k);
+    return v;
+}
+
+// One codeword at a time from bit `pos` to the subsequence's end, never past the stream's (the few lanes the stream begins
+// and ends in).  A codeword cut by the stream's end is nobody's; the exit then points at the stream's end, where the next
+// subsequence's walk stops at once (as walk_subsequence's, et_kernels.hip).
+// -> exit column | codewords << 8
+__device__ __attribute__((noinline)) uint32_t rs_slow_walk(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t pos, uint64_t sub_end, uint32_t t) {
+    const uint64_t n_bits = n_bytes * 8;
+    uint32_t n = 0;
+    bool cut = false;
+    while (pos < sub_end) {
+        if (pos + 7 > n_bits) {
+            cut = true;
+            break;
+        }
+        const uint64_t at = pos >> 3;
+        const uint32_t sh = static_cast<uint32_t>(pos & 7);
+        const uint32_t b0 = bytes[at], b1 = at + 1 < n_bytes ? bytes[at + 1] : 0u;
+        const uint32_t w8 = (((b0 << 8) | b1) >> (8 - sh)) & 0xffu;
+        const uint32_t len = (w8 >> 1) < t ? 7u : 8u;
+        if (pos + len > n_bits) {
+            cut = true;
+            break;
+        }
+        ++n;
+        pos += len;
+    }
+    const uint32_t exit_col = cut ? (n_bits > sub_end ? static_cast<uint32_t>(n_bits - sub_end) : 0u) : static_cast<uint32_t>(pos - sub_end);
+    return exit_col | (n << 8);
+}
+
+struct RsShared {
+    unsigned long long lane_pre[RS_CH][RS_THREADS];  // a lane's INCLUSIVE prefix map inside its wavefront
+    unsigned long long lane_cnt[RS_CH][RS_THREADS];  // codewords that begin in the lane's subsequence, per entry column (a byte each)
+    unsigned long long wave_map[RS_WAVES];           // a wavefront's map ...
+    unsigned long long wave_pre[RS_WAVES];           // ... and the map from the chunk's entry to the wavefront's
+    uint32_t wave_count[RS_WAVES];
+    uint32_t chunk, entry;
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, uint32_t n_blocks,
+                                                         uint32_t n_chunks, uint32_t code_t, unsigned long long *__restrict__ pub, uint32_t *__restrict__ ticket,
+                                                         uint32_t *__restrict__ fault, uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
+                                                         uint32_t *__restrict__ blk_count) {
+    __shared__ RsShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint64_t n_bits = n_bytes * 8, n_words_full = n_bytes / 4;
+    const uint32_t add_c = 0x01010101u * (128u - code_t);  // + this, and bit 7 of a byte says "its 7-bit value is >= t": an 8-bit code
+    for (;;) {
+        __syncthreads();  // everybody is done with the chunk before
+        if (tid == 0) sh.chunk = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t c = sh.chunk;
+        if (c >= n_chunks) break;
+        const uint32_t b_first = c * RS_CH, n_here = n_blocks - b_first < RS_CH ? n_blocks - b_first : RS_CH;
+
+        // ---- the lanes' maps, the wavefronts' prefix maps ------------------------------------------------------------------
+        for (uint32_t q = 0; q < n_here; ++q) {
+            const uint32_t b = b_first + q;
+            const uint64_t sub_g = static_cast<uint64_t>(b) * RS_THREADS + tid;
+            const bool live = sub_g < n_subs;
+            const uint64_t sub_end = (sub_g + 1) * 256;
+            uint32_t e_lo = ID_LO, e_hi = ID_HI, c_lo = 0, c_hi = 0;  // (a subsequence past the stream's end: nothing happens in it)
+            const bool slow = live && (sub_g == 0 || sub_end + 8 > n_bits);
+            if (live && !slow) {
+                uint32_t w[9];
+                const bool interior = static_cast<uint64_t>(b + 1) * 2048 + 1 <= n_words_full;  // wavefront-uniform
+                if (interior) {
+                    const uint32_t *src = words + sub_g * 8;  // (4-byte aligned; the compiler makes two 16-byte loads and one of 4 of it)
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) w[j] = src[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) w[j] = rs_load_guarded(words, sub_g * 8 + j, n_bytes);
+                }
+                // 1. four rows per register: t[k] = bytes k, 8 + k, 16 + k, 24 + k of the subsequence; the bytes behind them are
+                //    t[k + 1], and for k = 7 bytes 8, 16, 24, 32
+                uint32_t t[9];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int o = k >> 2;  // bytes k < 4 lie in the even words, the others in the odd ones
+                    const uint32_t sel = static_cast<uint32_t>(k & 3) | (static_cast<uint32_t>(4 + (k & 3)) << 8) | 0x0c0c0000u;
+                    const uint32_t p01 = perm(w[2 + o], w[0 + o], sel), p23 = perm(w[6 + o], w[4 + o], sel);
+                    t[k] = perm(p23, p01, 0x05040100u);
+                }
+                t[8] = perm(w[8], t[0], 0x04030201u);
+                // 2. S[r] bit j: the 7 bits at (row j, column r) are a 7-bit codeword (their value is < t)
+                uint32_t S[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    uint32_t longs = 0;  // bit 8 i + k: row 8 i + k holds an 8-bit code at column r
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        uint32_t v7;
+                        if (r == 0) v7 = (t[k] >> 1) & 0x7f7f7f7fu;
+                        else if (r == 1) v7 = t[k] & 0x7f7f7f7fu;
+                        else {
+                            const uint32_t m1 = 0x01010101u * ((0x7fu << (r - 1)) & 0x7fu), m2 = 0x01010101u * (0xffu >> (9 - r));
+                            v7 = ((t[k] << (r - 1)) & m1) | ((t[k + 1] >> (9 - r)) & m2);
+                        }
+                        const uint32_t s = v7 + add_c;  // (7-bit values: no carry leaves a byte)
+                        longs |= (s >> (7 - k)) & (0x01010101u << k);
+                    }
+                    S[r] = ~longs;
+                }
+                // 3. the path from every entry column: in column (c0 - t) & 7 at iteration t, to the next 7-bit code in it or to the end
+                bool lane_stuck = false;
+#pragma unroll
+                for (int c0 = 0; c0 < 8; ++c0) {
+                    uint32_t j0 = 0, wraps = 0, ex = static_cast<uint32_t>(c0);
+                    bool act = true;
+                    for (uint32_t lap = 0; lap < 6 && __any(act); ++lap) {  // (<= 32 + 5 steps: every step but the last is a 7-bit code in a row of its own, but for the <= 5 that share one)
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int col = (c0 - it) & 7;
+                            const uint32_t m = S[col] & (0xffffffffu << j0);
+                            const bool hit = act && m != 0;
+                            if (act && !hit) {
+                                ex = static_cast<uint32_t>(col);
+                                act = false;
+                            }
+                            const uint32_t j = static_cast<uint32_t>(__builtin_ctz(m | 0x80000000u));
+                            if (col == 0) {  // from column 0 a 7-bit code ends inside its own row: the next codeword begins at column 7 of it
+                                if (hit) {
+                                    ++wraps;
+                                    j0 = j;
+                                }
+                            } else if (hit) {
+                                if (j == 31) {  // the next row is the next subsequence's first
+                                    ex = static_cast<uint32_t>(col - 1);
+                                    act = false;
+                                } else {
+                                    j0 = j + 1;
+                                }
+                            }
+                            if (it < 7 && !__any(act)) break;
+                        }
+                    }
+                    lane_stuck = lane_stuck || act;
+                    const uint32_t cnt = 32u + wraps;
+                    if (c0 == 0) e_lo = ex, c_lo = cnt;
+                    else if (c0 < 4) e_lo |= ex << (8 * c0), c_lo |= cnt << (8 * c0);
+                    else if (c0 == 4) e_hi = ex, c_hi = cnt;
+                    else e_hi |= ex << (8 * (c0 - 4)), c_hi |= cnt << (8 * (c0 - 4));
+                }
+                if (lane_stuck) atomicOr(fault, 2u);  // (cannot happen: a path has at most 37 steps)
+            } else if (slow) {
+                // the stream's first subsequence (its first codeword begins at bit first_bit, whatever comes in) and the one or two
+                // the stream ends in: one codeword at a time
+                const uint8_t *bytes = reinterpret_cast<const uint8_t *>(words);
+                e_lo = e_hi = c_lo = c_hi = 0;
+                for (uint32_t c0 = 0; c0 < 8; ++c0) {
+                    uint32_t ex = 0, cnt = 0;
+                    if (sub_g == 0 && c0 > 0) {  // (a constant map)
+                        ex = e_lo & 0xffu;
+                        cnt = c_lo & 0xffu;
+                    } else {
+                        const uint32_t r = rs_slow_walk(bytes, n_bytes, sub_g == 0 ? first_bit : sub_g * 256 + c0, sub_end, code_t);
+                        ex = r & 0xffu;
+                        cnt = r >> 8;
+                    }
+                    if (c0 < 4) e_lo |= ex << (8 * c0), c_lo |= cnt << (8 * c0);
+                    else e_hi |= ex << (8 * (c0 - 4)), c_hi |= cnt << (8 * (c0 - 4));
+                }
+            }
+            // 4. inclusive scan of the wavefront's maps: pre_i = f_i o ... o f_0 (first f_0), by v_perm
+            uint32_t p_lo = e_lo, p_hi = e_hi;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o_lo = __shfl_up(p_lo, d), o_hi = __shfl_up(p_hi, d);  // the map of the lanes before
+                const uint32_t n_lo = perm(p_hi, p_lo, o_lo), n_hi = perm(p_hi, p_lo, o_hi);  // first theirs, then ours
+                if (lane >= static_cast<uint32_t>(d)) p_lo = n_lo, p_hi = n_hi;
+            }
+            sh.lane_pre[q][tid] = static_cast<unsigned long long>(p_lo) | (static_cast<unsigned long long>(p_hi) << 32);
+            sh.lane_cnt[q][tid] = static_cast<unsigned long long>(c_lo) | (static_cast<unsigned long long>(c_hi) << 32);
+            if (lane == 63) sh.wave_map[q * 4 + wv] = static_cast<unsigned long long>(p_lo) | (static_cast<unsigned long long>(p_hi) << 32);
+        }
+        __syncthreads();
+
+        // ---- the chunk's map, its entry column by look-back ---------------------------------------------------------------------
+        if (wv == 0) {
+            uint32_t f_lo = ID_LO, f_hi = ID_HI;
+            for (uint32_t k = 0; k < n_here * 4; ++k) {  // (every lane the same: 16 steps)
+                if (lane == 0) sh.wave_pre[k] = static_cast<unsigned long long>(f_lo) | (static_cast<unsigned long long>(f_hi) << 32);
+                const unsigned long long m = sh.wave_map[k];
+                const uint32_t m_lo = static_cast<uint32_t>(m), m_hi = static_cast<uint32_t>(m >> 32);
+                const uint32_t n_lo = perm(m_hi, m_lo, f_lo), n_hi = perm(m_hi, m_lo, f_hi);
+                f_lo = n_lo, f_hi = n_hi;
+            }
+            uint32_t entry = 0;  // (the stream's first chunk: its first lane's map is constant)
+            if (c > 0) {
+                const unsigned long long mine = (static_cast<unsigned long long>(f_lo) | (static_cast<unsigned long long>(f_hi) << 32)) | KIND_MAP;
+                if (lane == 0) __hip_atomic_store(pub + c, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // g: from the entry column of chunk i + 1 to ours; 64 chunks per look, nearest first
+                uint32_t g_lo = ID_LO, g_hi = ID_HI;
+                long long i = static_cast<long long>(c) - 1;
+                for (uint32_t spins = 0;;) {
+                    const long long idx = i - static_cast<long long>(lane);
+                    unsigned long long v = 0;
+                    if (idx >= 0) v = __hip_atomic_load(pub + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t kind = static_cast<uint32_t>(v >> 3) & 3u;
+                    const unsigned long long ready = __ballot(kind != 0), known = __ballot(kind == 2);
+                    const uint32_t n_ready = ~ready ? static_cast<uint32_t>(__builtin_ctzll(~ready)) : 64u;
+                    if (n_ready == 0) {
+                        if (++spins > RS_SPINS) {  // (a dead device; the launch still ends)
+                            if (lane == 0) atomicOr(fault, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                        continue;
+                    }
+                    const uint32_t first_known = known ? static_cast<uint32_t>(__builtin_ctzll(known)) : 64u;
+                    const uint32_t use = n_ready < first_known + 1 ? n_ready : first_known + 1;
+                    const uint32_t v_lo = static_cast<uint32_t>(v) & 0x07070707u, v_hi = static_cast<uint32_t>(v >> 32) & 0x07070707u;
+                    for (uint32_t l = 0; l < use; ++l) {  // g = g o (map of chunk i - l)
+                        const uint32_t m_lo = __builtin_amdgcn_readlane(v_lo, l), m_hi = __builtin_amdgcn_readlane(v_hi, l);
+                        const uint32_t n_lo = perm(g_hi, g_lo, m_lo), n_hi = perm(g_hi, g_lo, m_hi);
+                        g_lo = n_lo, g_hi = n_hi;
+                    }
+                    if (first_known < use) break;  // (g is constant now: the entry column)
+                    i -= use;
+                }
+                entry = g_lo & 7u;
+            }
+            const uint32_t out_col = map_at(f_lo, f_hi, entry);
+            if (lane == 0) {
+                __hip_atomic_store(pub + c, static_cast<unsigned long long>(out_col) * 0x0101010101010101ull | KIND_ENTRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh.entry = entry;
+            }
+        }
+        __syncthreads();
+
+        // ---- every lane's start, exit and count ----------------------------------------------------------------------------------
+        const uint32_t entry = sh.entry;
+        for (uint32_t q = 0; q < n_here; ++q) {
+            const uint32_t b = b_first + q;
+            const uint64_t sub_g = static_cast<uint64_t>(b) * RS_THREADS + tid;
+            const bool live = sub_g < n_subs;
+            const unsigned long long wp = sh.wave_pre[q * 4 + wv], lp = sh.lane_pre[q][tid], lc = sh.lane_cnt[q][tid];
+            const uint32_t wave_in = map_at(static_cast<uint32_t>(wp), static_cast<uint32_t>(wp >> 32), entry);
+            const uint32_t out_col = map_at(static_cast<uint32_t>(lp), static_cast<uint32_t>(lp >> 32), wave_in);  // behind this lane
+            const uint32_t before = __shfl_up(out_col, 1);
+            const uint32_t in_col = lane ? before : wave_in;
+            const uint32_t cnt = live ? map_at(static_cast<uint32_t>(lc), static_cast<uint32_t>(lc >> 32), in_col) : 0u;
+            if (live) sub_state[sub_g] = (sub_g == 0 ? first_bit : in_col) | (out_col << 8) | (cnt << 16);
+            uint32_t sum = cnt;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+            if (lane == 0) sh.wave_count[q * 4 + wv] = sum;
+            if (tid == RS_THREADS - 1) blk_exit[b] = out_col;
+        }
+        __syncthreads();
+        if (tid < n_here) blk_count[b_first + tid] = sh.wave_count[tid * 4] + sh.wave_count[tid * 4 + 1] + sh.wave_count[tid * 4 + 2] + sh.wave_count[tid * 4 + 3];
+    }
+}
+
+size_t row_sync_scratch_bytes(uint32_t n_blocks) {
+    const size_t n_chunks = (static_cast<size_t>(n_blocks) + RS_CH - 1) / RS_CH;
+    return n_chunks * sizeof(unsigned long long) + 64;
+}
+
+void launch_row_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, RowCode rc, void *scratch, uint32_t *fault,
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count) {
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + RS_THREADS - 1) / RS_THREADS);
+    const uint32_t n_chunks = (n_blocks + RS_CH - 1) / RS_CH;
+    if (!n_chunks) return;
+    (void)hipMemsetAsync(scratch, 0, row_sync_scratch_bytes(n_blocks), stream);  // "nothing published", ticket 0
+    unsigned long long *pub = static_cast<unsigned long long *>(scratch);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(pub + n_chunks);
+    static thread_local int seen_dev = -1, cus = 256;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != seen_dev) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        seen_dev = dev;
+    }
+    uint32_t grid = static_cast<uint32_t>(cus) * 8u;  // (workgroups that find no room wait their turn and take later tickets: nobody waits for them)
+    if (grid > n_chunks) grid = n_chunks;
+    hipLaunchKernelGGL(k_row_sync, dim3(grid), dim3(RS_THREADS), 0, stream, words, n_bytes, first_bit, n_subs, n_blocks, n_chunks, rc.t, pub, ticket, fault, sub_state, blk_exit,
+                       blk_count);
+}
+
+}  // namespace et

@@ -1,0 +1,208 @@
+"""GPU: the row walk (csrc/et_rowsync.hip) -- one-pass synchronisation of complete codes of 7 and 8 bits, the streams
+BASELINE.json calls its worst case (uniform bytes) -- against the oracle, through the C ABI.
+
+What a decode runs is asserted (timings()["row_sync"]), and so is the fallback for the same streams (ET_NO_ROW_SYNC=1 in a
+child process: the exit maps of et_kernels.hip), so both stay pinned."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle as O
+
+    return O
+
+
+def flat(k, n, seed, lo=None):
+    """n bytes over k distinct values with (almost) equal counts, shuffled: lengths 7 and 8 for 129 <= k <= 255."""
+    rng = np.random.default_rng(seed)
+    lo = (256 - k) // 2 if lo is None else lo
+    vals = (np.arange(k) + lo).astype(np.uint8)
+    data = np.tile(vals, n // k + 1)[:n]
+    rng.shuffle(data)
+    return data
+
+
+def _timed_decode(ctx, et):
+    ctx.enable_timing(True)
+    try:
+        back = ctx.decode(et[4:])
+        t = ctx.timings("decode")
+    finally:
+        ctx.enable_timing(False)
+    return back, t
+
+
+@pytest.mark.parametrize("k", [129, 130, 160, 200, 240, 250, 254, 255])
+def test_flat_alphabets_decode_by_rows(ctx, k):
+    """T = 256 - k seven-bit codes, from 127 down to 1: every share of short codes, paths that change column at
+    almost every row and paths that never do."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    data = flat(k, 300_007, 40 + k)
+    want = O.encode(data.tobytes())
+    cb, n, off = E.parse_header(want[4:])
+    assert cb.raw.max_length == 8 and cb.raw.min_length == 7 and cb.raw.n_coded == k
+    assert ctx.encode(data.tobytes()) == want
+    back, t = _timed_decode(ctx, want)
+    assert t["row_sync"] and t["exhaustive_sync"] and t["chained_write"]
+    assert back == data.tobytes()
+
+
+def test_sizes_around_subsequences_blocks_and_chunks(ctx):
+    """Stream ends everywhere around a 256-bit subsequence, an 8 KiB block and a ticket's chunk of blocks (the lanes the
+    stream ends in walk one codeword at a time; chunks and blocks may be partly or wholly empty).  The code is fixed
+    (255 symbols of equal weight), the body packed by the oracle, so any number of symbols will do."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    h = np.zeros(256, dtype=np.uint64)
+    h[1:] = 100
+    cb = E.Codebook.from_histogram(h)
+    assert cb.raw.max_length == 8 and cb.raw.min_length == 7 and cb.raw.n_coded == 255
+    chunk_text = 4 * 8192  # ~symbols per chunk (codes are ~8 bits)
+    sizes = [1, 2, 3, 4, 5, 31, 32, 33, 34, 63, 64, 65, 255, 256, 257, 8190, 8192, 8200, 8224, 8225, 8226, 8192 * 2 + 5, chunk_text - 40, chunk_text - 1, chunk_text,
+             chunk_text + 1, chunk_text + 129, chunk_text + 300, 2 * chunk_text + 17, 5 * chunk_text - 3, 1_000_003]
+    sizes += list(range(8192 - 12, 8192 + 48))  # every end position around the first block's end (7.97 bits per symbol)
+    base = flat(255, max(sizes) + 1000, 7, lo=1)
+    out = torch.empty(max(sizes) + 64, dtype=torch.uint8, device="cuda")
+    for n in sizes:
+        data = base[:n]
+        body, end_bit = O.pack_body(cb.data, cb.length, data, 0)
+        buf = torch.frombuffer(bytearray(body) + bytearray(64), dtype=torch.uint8).cuda()
+        ctx.enable_timing(True)
+        try:
+            m = ctx.decode_body_device(cb, buf[: (end_bit + 7) // 8], n, out, 0)
+            t = ctx.timings("decode")
+        finally:
+            ctx.enable_timing(False)
+        assert t["row_sync"], n
+        assert m == n and out[:m].cpu().numpy().tobytes() == data.tobytes(), n
+
+
+def test_every_truncation_of_a_small_stream(ctx):
+    """Truncated streams: the codeword the stream's end cuts is nobody's, wherever in a row, a subsequence or a block the
+    end falls (the oracle's intended decoder decides)."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    data = flat(200, 9_000, 3)
+    et = O.encode(data.tobytes())[4:]
+    _, _, off = E.parse_header(et)
+    checked = 0
+    for cut in list(range(off + 1, off + 80)) + list(range(len(et) - 300, len(et))) + list(range(off + 8100, off + 8300, 3)):
+        part = et[:cut]
+        assert ctx.decode(part) == O.decode(part), cut
+        checked += 1
+    assert checked > 400
+
+
+def test_body_alignments_and_start_bits(ctx):
+    """The body from any byte offset (its 4-byte aligned base lies up to 3 bytes before it) and any start bit: the stream's
+    first codeword begins at bit first_bit < 32 of the first subsequence."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    data = flat(255, 70_001, 11, lo=1)
+    h = np.bincount(data, minlength=256).astype(np.uint64)
+    cb = E.Codebook.from_histogram(h)
+    assert cb.raw.max_length == 8 and cb.raw.min_length == 7
+    for start_bit in range(8):
+        body, end_bit = O.pack_body(cb.data, cb.length, data, start_bit)
+        for shift in range(4):
+            buf = torch.zeros(len(body) + 64, dtype=torch.uint8, device="cuda")
+            buf[16 + shift : 16 + shift + len(body)] = torch.frombuffer(bytearray(body), dtype=torch.uint8).cuda()
+            out = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+            ctx.enable_timing(True)
+            try:
+                m = ctx.decode_body_device(cb, buf[16 + shift : 16 + shift + (end_bit + 7) // 8], data.size, out, start_bit)
+                t = ctx.timings("decode")
+            finally:
+                ctx.enable_timing(False)
+            assert t["row_sync"]
+            assert m == data.size and out[:m].cpu().numpy().tobytes() == data.tobytes(), (start_bit, shift)
+
+
+def test_fuzzed_bodies_match_the_oracle(ctx):
+    """Bit flips, junk and all-ones / all-zeros runs in the body: any bit pattern is a codeword of a complete code, so the
+    decode is whatever the bits say -- and equals the oracle's."""
+    import entreepy_amd as E
+
+    O = _oracle()
+    rng = np.random.default_rng(99)
+    for trial in range(10):
+        k = int(rng.choice([129, 180, 254, 255]))
+        data = flat(k, int(rng.integers(30_000, 300_000)), 100 + trial)
+        good = bytearray(O.encode(data.tobytes())[4:])
+        _, _, off = E.parse_header(bytes(good))
+        kind = trial % 4
+        if kind == 0:
+            for pos in rng.integers(off, len(good), size=60):
+                good[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            a = int(rng.integers(off, len(good) - 5000))
+            good[a : a + 4096] = rng.integers(0, 256, size=4096, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            del good[int(rng.integers(off + 1, len(good))) :]
+        else:
+            good[-9000:-4500] = b"\xff" * 4500
+            good[-4500:] = b"\x00" * 4500
+        assert ctx.decode(bytes(good)) == O.decode(bytes(good)), (trial, kind, k)
+
+
+def test_large_stream_many_chunks_in_flight(ctx):
+    """256 MiB of 255 uniform byte values: ~8000 chunks, thousands in flight at once, look-backs over whatever has been
+    published -- an exact round trip, twice (the second run finds the scratch words of the first)."""
+    import torch
+
+    import entreepy_amd as E
+
+    n = 256 << 20
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    text = torch.randint(1, 256, (n,), generator=g, device="cuda", dtype=torch.int16).to(torch.uint8)
+    enc = torch.zeros(E.encode_bound(n) + 64, dtype=torch.uint8, device="cuda")
+    dec = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    et_len = ctx.encode_device(text, enc)
+    for _ in range(2):
+        dec.zero_()
+        ctx.enable_timing(True)
+        try:
+            m = ctx.decode_device(enc[4:et_len], dec)
+            t = ctx.timings("decode")
+        finally:
+            ctx.enable_timing(False)
+        assert t["row_sync"]
+        assert m == n and torch.equal(dec[:n], text)
+
+
+def test_fallback_exit_maps_still_decode_these_streams():
+    """ET_NO_ROW_SYNC=1 (a child process: the switch is read once): the same streams through k_dec_maps_reg / k_dec_resolve_reg."""
+    code = (
+        "import numpy as np, entreepy_amd as E\n"
+        "from tests.test_gpu_rowsync import flat\n"
+        "from oracle import oracle as O\n"
+        "c = E.Context(0); c.enable_timing(True)\n"
+        "for k in (130, 255):\n"
+        "    d = flat(k, 400_003, k)\n"
+        "    et = O.encode(d.tobytes())\n"
+        "    assert c.decode(et[4:]) == d.tobytes()\n"
+        "    t = c.timings('decode')\n"
+        "    assert t['exhaustive_sync'] and not t['row_sync'], t\n"
+        "print('ok')\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, ET_NO_ROW_SYNC="1"), timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -389,3 +389,42 @@ def test_chain_tables_decode_what_the_codes_say():
             stream += [(int(cb.data[s]) >> i) & 1 for i in range(L - 1, -1, -1)]
         got, pos = _decode_through_chain(table, stream, text.size)
         assert got == [int(s) for s in text]
+
+
+def test_row_code_is_the_flat_codes_of_the_reference_builder_only():
+    """et_row_code (csrc/et_rowsync_host.cpp): which dictionaries a decode synchronises by rows and columns -- complete codes
+    of 7 and 8 bits whose 7-bit codewords are the values 0 .. t-1.  The reference's builder gives exactly that for k = 129 .. 255
+    symbols of equal weight (t = 256 - k); anything else goes the general way."""
+    import ctypes
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+
+    def row_t(cb):
+        t = ctypes.c_uint32(0xdead)
+        rc = N.lib().et_row_code(ctypes.byref(cb.raw), ctypes.byref(t))
+        assert rc in (N.ET_OK, N.ET_ERR_UNSUPPORTED)
+        return t.value if rc == N.ET_OK else None
+
+    for k in (129, 130, 200, 254, 255):
+        h = np.zeros(256, dtype=np.uint64)
+        h[:k] = 1000
+        cb = E.Codebook.from_histogram(h)
+        assert row_t(cb) == 256 - k, k
+        # the same code with its 7-bit codewords elsewhere (bitwise complement of every codeword: still complete and
+        # prefix-free, but they are now the LAST values): not a row code
+        length, data = cb.length, cb.data
+        flipped = np.where(length > 0, (~data) & ((1 << length.astype(np.uint32)) - 1), 0).astype(np.uint32)
+        assert row_t(E.Codebook.from_tables(flipped, length)) is None, k
+    # 256 symbols of 8 bits each (a hand-made dictionary: the reference's own encoder drops one of 256, SURVEY Q1): t = 0
+    full = E.Codebook.from_tables(np.arange(256, dtype=np.uint32), np.full(256, 8, dtype=np.uint8))
+    assert row_t(full) == 0
+    # not complete / other lengths / text
+    gap = E.Codebook.from_tables(np.arange(256, dtype=np.uint32), np.where(np.arange(256) < 255, 8, 0).astype(np.uint8))
+    assert row_t(gap) is None
+    h = np.zeros(256, dtype=np.uint64)
+    h[:100] = 7
+    assert row_t(E.Codebook.from_histogram(h)) is None  # 6 and 7 bits
+    from tests import corpus
+
+    assert row_t(E.Codebook.from_histogram(np.bincount(corpus.text_like(100_000, 1), minlength=256))) is None

@@ -10,9 +10,10 @@ rm -rf $out variants/libet_head.so
 mkdir -p $out
 git archive $rev entreepy_amd/csrc include | tar -x -C $src
 HIPCC=/opt/rocm/bin/hipcc
+SRCDIR=$src/entreepy_amd/csrc
 CXX="-O3 -std=c++17 -fPIC -I$src/include -I$src/entreepy_amd/csrc"
-for f in et_kernels et_treewalk; do $HIPCC $CXX --offload-arch=gfx950 -c $src/entreepy_amd/csrc/$f.hip -o $out/$f.o & done
-for f in et_treewalk_host et_api et_codebook et_io et_tables et_shard_seq et_shard_hip; do $HIPCC $CXX -c $src/entreepy_amd/csrc/$f.cpp -o $out/$f.o & done
+for f in $(cd $SRCDIR && ls *.hip | sed s/.hip//); do $HIPCC $CXX --offload-arch=gfx950 -c $src/entreepy_amd/csrc/$f.hip -o $out/$f.o & done
+for f in $(cd $SRCDIR && ls *.cpp | grep -v entreepy_cli | sed s/.cpp//); do $HIPCC $CXX -c $src/entreepy_amd/csrc/$f.cpp -o $out/$f.o & done
 wait
 $HIPCC -shared -fPIC --offload-arch=gfx950 -o variants/libet_head.so $out/*.o -lpthread -ldl
 rm -rf $out $src

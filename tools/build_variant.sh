@@ -9,9 +9,10 @@ name=$1; flags=$2
 out=variants/build_$name
 mkdir -p $out
 HIPCC=/opt/rocm/bin/hipcc
+SRCDIR=entreepy_amd/csrc
 CXX="-O3 -std=c++17 -fPIC -Iinclude -Ientreepy_amd/csrc $flags"
-for f in et_kernels et_treewalk; do $HIPCC $CXX --offload-arch=gfx950 -c entreepy_amd/csrc/$f.hip -o $out/$f.o & done
-for f in et_treewalk_host et_api et_codebook et_io et_tables et_shard_seq et_shard_hip; do $HIPCC $CXX -c entreepy_amd/csrc/$f.cpp -o $out/$f.o & done
+for f in $(cd $SRCDIR && ls *.hip | sed s/.hip//); do $HIPCC $CXX --offload-arch=gfx950 -c entreepy_amd/csrc/$f.hip -o $out/$f.o & done
+for f in $(cd $SRCDIR && ls *.cpp | grep -v entreepy_cli | sed s/.cpp//); do $HIPCC $CXX -c entreepy_amd/csrc/$f.cpp -o $out/$f.o & done
 wait
 $HIPCC -shared -fPIC --offload-arch=gfx950 -o variants/libet_$name.so $out/*.o -lpthread -ldl
 echo "variants/libet_$name.so"
