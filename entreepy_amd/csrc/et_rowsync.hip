@@ -4,8 +4,10 @@
 //
 // A lane owns a subsequence = 32 rows (bytes) x 8 columns (bit offsets).  It
 //   1. transposes its 32 bytes so that four rows sit in one register (24 v_perm),
-//   2. works out S[r], r = 0..7: bit j of S[r] says "the 7 bits at row j, column r are a 7-bit codeword" -- a byte-parallel add
-//      and mask per four rows, 7 VALU instructions per (four rows, column), no lookups,
+//   2. turns them into 15 bit PLANES (bit j of plane c = bit c of row j, or of the row below for c >= 8: 2 instructions per four
+//      rows and plane) and works out S[r], r = 0..7: bit j of S[r] says "the 7 bits at row j, column r are a 7-bit codeword" --
+//      a comparator of planes r .. r + 6 against t from the top bit down, 32 rows per instruction, no lookups (a first version
+//      compared byte-parallel, four rows per instruction: 425 of the lane's 760 VALU instructions; this one takes ~250),
 //   3. follows, for each of the 8 columns a walk can enter the subsequence in, the path to the subsequence's end: a path stays
 //      in its column until the next set bit of S[column] (v_ffbl), then moves one column to the left.  ALL lanes' paths visit the
 //      columns in the same order, so iteration t of the walk from column c works on the register S[(c - t) & 7] in every lane:
@@ -95,7 +97,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
     __shared__ RsShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t n_bits = n_bytes * 8, n_words_full = n_bytes / 4;
-    const uint32_t add_c = 0x01010101u * (128u - code_t);  // + this, and bit 7 of a byte says "its 7-bit value is >= t": an 8-bit code
     for (;;) {
         __syncthreads();  // everybody is done with the chunk before
         if (tid == 0) sh.chunk = atomicAdd(ticket, 1u);
@@ -123,9 +124,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
 #pragma unroll
                     for (int j = 0; j < 9; ++j) w[j] = rs_load_guarded(words, sub_g * 8 + j, n_bytes);
                 }
-                // 1. four rows per register: t[k] = bytes k, 8 + k, 16 + k, 24 + k of the subsequence; the bytes behind them are
-                //    t[k + 1], and for k = 7 bytes 8, 16, 24, 32
-                uint32_t t[9];
+                // 1. four rows per register: t[k] = bytes k, 8 + k, 16 + k, 24 + k of the subsequence
+                uint32_t t[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int o = k >> 2;  // bytes k < 4 lie in the even words, the others in the odd ones
@@ -133,56 +133,63 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
                     const uint32_t p01 = perm(w[2 + o], w[0 + o], sel), p23 = perm(w[6 + o], w[4 + o], sel);
                     t[k] = perm(p23, p01, 0x05040100u);
                 }
-                t[8] = perm(w[8], t[0], 0x04030201u);
-                // 2. S[r] bit j: the 7 bits at (row j, column r) are a 7-bit codeword (their value is < t)
-                uint32_t S[8];
+                // 2. bit planes: bit j of B[c] = bit c (from the top) of row j, c = 0..7; c = 8..14: the same bits of row j + 1 (the
+                //    seven bits behind the row's own) -- 2 instructions per (four rows, bit)
+                uint32_t B[15];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    uint32_t longs = 0;  // bit 8 i + k: row 8 i + k holds an 8-bit code at column r
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t acc = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        uint32_t v7;
-                        if (r == 0) v7 = (t[k] >> 1) & 0x7f7f7f7fu;
-                        else if (r == 1) v7 = t[k] & 0x7f7f7f7fu;
-                        else {
-                            const uint32_t m1 = 0x01010101u * ((0x7fu << (r - 1)) & 0x7fu), m2 = 0x01010101u * (0xffu >> (9 - r));
-                            v7 = ((t[k] << (r - 1)) & m1) | ((t[k + 1] >> (9 - r)) & m2);
-                        }
-                        const uint32_t s = v7 + add_c;  // (7-bit values: no carry leaves a byte)
-                        longs |= (s >> (7 - k)) & (0x01010101u << k);
+                    for (int k = 0; k < 8; ++k) {  // bit 7 - c of byte lane i of t[k] -> bit 8 i + k
+                        const int up = k - (7 - c);
+                        const uint32_t moved = up >= 0 ? t[k] << up : t[k] >> -up;
+                        acc |= moved & (0x01010101u << k);
                     }
-                    S[r] = ~longs;
+                    B[c] = acc;
                 }
-                // 3. the path from every entry column: in column (c0 - t) & 7 at iteration t, to the next 7-bit code in it or to the end
+#pragma unroll
+                for (int c = 0; c < 7; ++c) B[8 + c] = __builtin_amdgcn_alignbit(w[8] >> (7 - c), B[c], 1);  // rows 1..31 of plane c, then byte 32's bit
+                // 3. S[r] bit j: the 7 bits at (row j, column r) -- planes r .. r + 6 -- are a 7-bit codeword: their value is < t.
+                //    A comparator over the planes from the top bit down, 32 rows per instruction; t's bits are the same for everybody.
+                uint32_t S[8], eq[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) S[r] = 0, eq[r] = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    if ((code_t >> (6 - i)) & 1u) {  // t has a 1 here: rows with a 0 (and equal so far) are below t; the others stay equal
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            S[r] |= eq[r] & ~B[r + i];
+                            eq[r] &= B[r + i];
+                        }
+                    } else {  // t has a 0 here: rows with a 1 are above it
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) eq[r] &= ~B[r + i];
+                    }
+                }
+                // 4. the path from every entry column: in column (c0 - it) & 7 at iteration `it`, down to the next 7-bit code in that
+                //    column (then one column to the left, from the row below) or to the subsequence's end.  `rows` = the rows still
+                //    ahead of the path in the column it is about to look at.  Straight-line code, nothing indexed, no divergence.
                 bool lane_stuck = false;
 #pragma unroll
                 for (int c0 = 0; c0 < 8; ++c0) {
-                    uint32_t j0 = 0, wraps = 0, ex = static_cast<uint32_t>(c0);
+                    uint32_t rows = 0xffffffffu, wraps = 0, ex = static_cast<uint32_t>(c0);
                     bool act = true;
-                    for (uint32_t lap = 0; lap < 6 && __any(act); ++lap) {  // (<= 32 + 5 steps: every step but the last is a 7-bit code in a row of its own, but for the <= 5 that share one)
+                    for (uint32_t lap = 0; lap < 6 && __any(act); ++lap) {  // (<= 32 + 5 steps: all but the last are 7-bit codes, each in a row of its own but for <= 5)
 #pragma unroll
                         for (int it = 0; it < 8; ++it) {
                             const int col = (c0 - it) & 7;
-                            const uint32_t m = S[col] & (0xffffffffu << j0);
-                            const bool hit = act && m != 0;
-                            if (act && !hit) {
-                                ex = static_cast<uint32_t>(col);
-                                act = false;
-                            }
-                            const uint32_t j = static_cast<uint32_t>(__builtin_ctz(m | 0x80000000u));
-                            if (col == 0) {  // from column 0 a 7-bit code ends inside its own row: the next codeword begins at column 7 of it
-                                if (hit) {
-                                    ++wraps;
-                                    j0 = j;
-                                }
-                            } else if (hit) {
-                                if (j == 31) {  // the next row is the next subsequence's first
-                                    ex = static_cast<uint32_t>(col - 1);
-                                    act = false;
-                                } else {
-                                    j0 = j + 1;
-                                }
-                            }
+                            const uint32_t m = S[col] & rows;
+                            const bool some = m != 0, hit = act && some;
+                            ex = (act && !some) ? static_cast<uint32_t>(col) : ex;  // nothing more in this column: the path leaves the subsequence in it
+                            act = hit;
+                            uint32_t j;
+                            asm("v_ffbl_b32 %0, %1" : "=v"(j) : "v"(m));
+                            // a 7-bit code at (j, col) ends at (j + 1, col - 1): the rows below j -- from column 0 it ends at (j, 7): row j too.
+                            // (from row 31 nothing is left below: the next iteration finds nothing and records column col - 1)
+                            const uint32_t below = (col == 0 ? 0xffffffffu : 0xfffffffeu) << j;
+                            rows = hit ? below : rows;
+                            if (col == 0) wraps += hit ? 1u : 0u;  // two codewords begin in row j
                             if (it < 7 && !__any(act)) break;
                         }
                     }
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
                     else e_hi |= ex << (8 * (c0 - 4)), c_hi |= cnt << (8 * (c0 - 4));
                 }
             }
-            // 4. inclusive scan of the wavefront's maps: pre_i = f_i o ... o f_0 (first f_0), by v_perm
+            // 5. inclusive scan of the wavefront's maps: pre_i = f_i o ... o f_0 (first f_0), by v_perm
             uint32_t p_lo = e_lo, p_hi = e_hi;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
