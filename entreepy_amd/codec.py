@@ -133,15 +133,19 @@ def encode_bound(n):
 class Context:
     """One et_ctx: a GPU's stream, workspaces and pinned staging.
 
-    A new context runs on a non-blocking stream of its OWN.  The *_device calls are ordered on that stream only:
-    a torch tensor produced on torch's current stream (a clone, a copy, a kernel) is not waited for.  Call
-    use_torch_stream() to run on torch's current stream instead (sharded.ShardedCodec and the tests' fixture do), or
-    synchronise before handing such tensors in."""
+    The *_device calls (and a Group's) take torch tensors, which torch's CURRENT stream produced and will consume, so by
+    default they run on that stream: whatever stream is current when the call is made (torch.cuda.stream(...) included) is
+    the one the call is ordered on -- no synchronisation is ever needed around them.  (Until round 4 a new context ran on a
+    non-blocking stream of its own unless told otherwise, and a caller who forgot use_torch_stream() raced with the kernels
+    that made its tensors: tests/soak/soak_sharded.py found that the hard way.)  use_own_stream() / use_stream(ptr) opt out:
+    the caller then orders the streams itself.  The C ABI is unchanged: an et_ctx starts on its own stream (et_ctx_set_stream)."""
 
     def __init__(self, device=0):
         self._h = ctypes.c_void_p()
         self.device = device
         self._groups = []  # weak references to the Groups made on this context: closed before it
+        self._follow_torch = True  # device calls bind the ctx to torch's current stream first
+        self._bound = None
         _check(N.lib().et_ctx_create(device, ctypes.byref(self._h)))
 
     def close(self):
@@ -168,16 +172,32 @@ class Context:
 
     # -- plumbing ---------------------------------------------------------------
     def use_stream(self, hip_stream):
-        """Run on a caller-owned stream, e.g. torch.cuda.current_stream().cuda_stream."""
+        """Run on a caller-owned stream (a raw hipStream_t); the caller orders it against the streams its tensors live on."""
+        self._follow_torch = False
+        self._bound = None
         _check(N.lib().et_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream)), self._h)
 
     def use_own_stream(self):
+        """Run on the context's own non-blocking stream; the caller orders it against the streams its tensors live on."""
+        self._follow_torch = False
+        self._bound = None
         _check(N.lib().et_ctx_use_own_stream(self._h), self._h)
 
     def use_torch_stream(self):
+        """(The default.)  Every device call runs on the stream that is torch's current one when the call is made."""
+        self._follow_torch = True
+        self._bind()
+
+    def _bind(self):
+        """Before a call that takes device tensors: the ctx onto torch's current stream (a pointer compare when nothing changed)."""
+        if not self._follow_torch:
+            return
         import torch
 
-        self.use_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        ptr = torch.cuda.current_stream(self.device).cuda_stream
+        if ptr != self._bound:
+            _check(N.lib().et_ctx_set_stream(self._h, ctypes.c_void_p(ptr)), self._h)
+            self._bound = ptr
 
     def reserve(self, max_text_bytes):
         _check(N.lib().et_ctx_reserve(self._h, int(max_text_bytes)), self._h)
@@ -260,12 +280,14 @@ class Context:
     def encode_device(self, text, out):
         """text, out: 1-D uint8 CUDA tensors; out.numel() >= encode_bound(text.numel()).
         Stream-ordered: returns the .et byte count without waiting for the kernels."""
+        self._bind()
         n = ctypes.c_size_t(0)
         _check(N.lib().et_encode_device(self._h, text.data_ptr(), text.numel(), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
         return n.value
 
     def decode_device(self, compressed_text, out, skip=0, length=None):
         """compressed_text[skip : skip + length] (default: to its end) -> out; the offsets spare the caller a tensor view."""
+        self._bind()
         n = ctypes.c_size_t(0)
         length = compressed_text.numel() - skip if length is None else length
         _check(N.lib().et_decode_device(self._h, compressed_text.data_ptr() + skip, length, out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
@@ -274,6 +296,7 @@ class Context:
     # -- staged calls (sharded encode) ----------------------------------------------
     def histogram_device(self, text, hist):
         """text: uint8 CUDA tensor; hist: int64/uint64 CUDA tensor of 256 counters."""
+        self._bind()
         assert hist.numel() == 256 and hist.element_size() == 8
         _check(N.lib().et_histogram_device(self._h, text.data_ptr(), text.numel(), hist.data_ptr()), self._h)
 
@@ -290,6 +313,7 @@ class Context:
         _check(N.lib().et_histogram_on_host(self._h, c.ctypes.data), self._h)
 
     def encode_body_device(self, codebook, text, out, start_bit=0):
+        self._bind()
         end = ctypes.c_uint64(0)
         _check(N.lib().et_encode_body_device(self._h, ctypes.byref(codebook.raw), text.data_ptr(), text.numel(), out.data_ptr(),
                                              out.numel() * out.element_size(), int(start_bit), ctypes.byref(end)), self._h)
@@ -297,6 +321,7 @@ class Context:
 
     def encode_head_shard_device(self, codebook, text, out, header):
         """Shard 0 of a sharded encode: file header followed by the shard's body."""
+        self._bind()
         end = ctypes.c_uint64(0)
         hb = np.frombuffer(header, dtype=np.uint8)
         _check(N.lib().et_encode_head_shard_device(self._h, ctypes.byref(codebook.raw), text.data_ptr(), text.numel(), out.data_ptr(),
@@ -304,6 +329,7 @@ class Context:
         return end.value
 
     def decode_body_device(self, codebook, body, n_symbols, out, start_bit=0):
+        self._bind()
         n = ctypes.c_size_t(0)
         _check(N.lib().et_decode_body_device(self._h, ctypes.byref(codebook.raw), body.data_ptr(), body.numel(), int(start_bit),
                                              int(n_symbols), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
@@ -316,6 +342,7 @@ class Context:
         begin a multiple of 8192, end too unless it is the stream's end).  Call again with
         the predecessor's exit as in_start_bit to repair.  -> dict(start_bit, exit_bit,
         n_symbols, sweeps)."""
+        self._bind()
         info = N.RangeInfo()
         tail = stream.numel() - end
         _check(N.lib().et_decode_range_sync(self._h, ctypes.byref(codebook.raw), stream.data_ptr() + begin, end - begin, tail,
@@ -328,6 +355,7 @@ class Context:
         -> (map, n_starts), map[p] = exit bit of the range when its first codeword begins
         p bits in (p < n_starts; constant when in_start_bit >= 0).  Follow with
         decode_range_resolve(start) once the start is known."""
+        self._bind()
         m = (ctypes.c_uint8 * 32)()
         k = ctypes.c_uint32(0)
         tail = stream.numel() - end
@@ -336,11 +364,13 @@ class Context:
         return bytes(m), k.value
 
     def decode_range_resolve(self, in_start_bit):
+        self._bind()
         info = N.RangeInfo()
         _check(N.lib().et_decode_range_resolve(self._h, int(in_start_bit), ctypes.byref(info)), self._h)
         return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps}
 
     def decode_range_write(self, max_symbols, out):
+        self._bind()
         n = ctypes.c_size_t(0)
         _check(N.lib().et_decode_range_write(self._h, int(max_symbols), out.data_ptr(), out.numel(), ctypes.byref(n)), self._h)
         return n.value
@@ -393,6 +423,12 @@ class Group:
         except Exception:  # noqa: BLE001 -- reported to the C caller as a failed exchange
             return 1
 
+    def _bind_ctx(self):
+        """The group's context onto torch's current stream (Context._bind); the CPU stand-in's contexts have no stream."""
+        b = getattr(self.ctx, "_bind", None)
+        if b is not None:
+            b()
+
     def _ck(self, status):
         if status == N.ET_OK:
             return
@@ -429,21 +465,26 @@ class Group:
 
     def encode_sharded(self, text, out):
         """et_encode_sharded: this rank's chunk (uint8 tensor, may be empty) -> its piece of the image in `out`."""
+        self._bind_ctx()
         i = N.ShardInfo()
         self._ck(self._lib.et_encode_sharded(self._h, self._ptr(text), text.numel(), out.data_ptr() if out is not None else None,
                                              out.numel() if out is not None else 0, ctypes.byref(i)))
         return self._info(i)
 
     def merge_seams(self, out):
+        self._bind_ctx()
         self._ck(self._lib.et_shard_merge_seams(self._h, out.data_ptr() if out is not None else None))
 
     def write_fd(self, out, fd):
+        self._bind_ctx()
         self._ck(self._lib.et_shard_write_fd(self._h, out.data_ptr(), fd))
 
     def place(self, out, image):
+        self._bind_ctx()
         self._ck(self._lib.et_shard_place(self._h, out.data_ptr(), image.data_ptr(), image.numel()))
 
     def gather(self, out, image, root=0):
+        self._bind_ctx()
         self._ck(self._lib.et_shard_gather(self._h, out.data_ptr(), image.data_ptr() if image is not None else None,
                                            image.numel() if image is not None else 0, root))
 
@@ -464,6 +505,7 @@ class Group:
 
     def decode_sharded(self, compressed_text, out):
         """et_decode_sharded: this rank's block range of one cold stream -> (symbols written, index of the first)."""
+        self._bind_ctx()
         n = ctypes.c_size_t(0)
         first = ctypes.c_uint64(0)
         self._ck(self._lib.et_decode_sharded(self._h, self._ptr(compressed_text), compressed_text.numel() if compressed_text is not None else 0,
@@ -481,6 +523,7 @@ class Group:
     def decode_begin(self, head, length, window, window_off, cap=None):
         """et_decode_sharded_begin (collective): window = uint8 tensor holding bytes [window_off, ...) of `compressed`
         -> (symbols this rank writes, index of the first)."""
+        self._bind_ctx()
         a, p = _host_u8(head) if head is not None else (np.zeros(0, dtype=np.uint8), None)
         n, first = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._ck(self._lib.et_decode_sharded_begin(self._h, p, a.size, int(length), self._ptr(window), int(window_off), window.numel() if window is not None else 0,
@@ -488,6 +531,7 @@ class Group:
         return n.value, first.value
 
     def decode_write(self, out):
+        self._bind_ctx()
         n = ctypes.c_size_t(0)
         self._ck(self._lib.et_decode_sharded_write(self._h, out.data_ptr() if out is not None else None, out.numel() if out is not None else 0, ctypes.byref(n)))
         return n.value

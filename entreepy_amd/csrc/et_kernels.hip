@@ -2182,6 +2182,19 @@ constexpr uint32_t WV_STAGE_ALLOC = WV_STAGE + 32;
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return __builtin_amdgcn_readlane(wave_inclusive_scan(x), 63); }
 
+// (round-4 probe, timing only -- wrong offsets: what D3 would load if D1 handed it per-quarter prefixes: its own state word, not the four quarters')
+// (round-4 probe, timing only -- wrong output: the write pass with its stream words served from the L2 (the stream's first 64 KiB over and
+// over): the floor of the write PHASE of a kernel that has the block in registers already and loads nothing)
+#ifdef ET_PROBE_D3_L2_LOADS
+#define ET_PROBE_D3_SRC(sub_) (((sub_) & 2047u) + 16u)
+#else
+#define ET_PROBE_D3_SRC(sub_) (sub_)
+#endif
+#ifdef ET_PROBE_D3_ONE_STATE
+#define ET_PROBE_ONE_STATE_COND &&q == quarter_
+#else
+#define ET_PROBE_ONE_STATE_COND
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                               const uint2 *__restrict__ chain, uint32_t n_entries,
@@ -2222,7 +2235,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
         n_edge = block_limit(n_bytes, b_) != 0xffffffffu;                                                         \
         _Pragma("unroll") for (uint32_t q = 0; q < 4; ++q) {                                                      \
             const uint64_t sg = b_ * BLOCK + q * 64 + lane;                                                       \
-            n_stq[q] = sg < n_subs ? sub_state[sg] : 0u;                                                          \
+            n_stq[q] = (sg < n_subs ET_PROBE_ONE_STATE_COND) ? sub_state[sg] : 0u;                                \
         }                                                                                                         \
         const uint64_t sub_g_ = b_ * BLOCK + quarter_ * 64 + lane;                                                \
         if (sub_g_ < n_subs) {                                                                                    \
@@ -2230,7 +2243,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
                 _Pragma("unroll") for (int j = 0; j < RW_WORDS; ++j)                                              \
                     n_W[j] = j < 4 ? 0u : __builtin_bswap32(load_be32_guarded(words, sub_g_ * (SUB_BITS / 32) - 4 + j, n_bytes)); \
             } else { /* (as they lie in memory: swapped when they are taken) */                                   \
-                const uint32_t *src_ = words + sub_g_ * (SUB_BITS / 32) - 4;                                      \
+                const uint32_t *src_ = words + ET_PROBE_D3_SRC(sub_g_) * (SUB_BITS / 32) - 4;                     \
                 _Pragma("unroll") for (int j = 0; j < RW_WORDS; ++j) n_W[j] = j < 4 ? 0u : src_[j];               \
             }                                                                                                     \
         } else {                                                                                                  \
@@ -2782,8 +2795,15 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     if (chain) {  // every block, one launch, no side lane, no ticket; `tb` is not looked at
         // 8 wavefronts per workgroup share the tables (17 KiB) beside their 4 KiB stages: 3 workgroups = 24 wavefronts per CU
+#ifdef ET_PROBE_FUSED_OCC  // (round-4 probe, DESIGN section 4: the write pass at the occupancy a kernel that also holds D1's tree table would have -- one workgroup of ET_PROBE_FUSED_OCC wavefronts per CU)
+        constexpr int WAVES = ET_PROBE_FUSED_OCC;
+#else
         constexpr int WAVES = 8;  // (12 x 2 per CU the same; 16 x 2 with 3.8 KiB stages, 32 wavefronts per CU, the same too: 0.441-0.445 ms; 4 x 4 or 16 x 1: 0.56)
-        const size_t smem_wave = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + WAVES * WV_STAGE_ALLOC;
+#endif
+        size_t smem_wave = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + WAVES * WV_STAGE_ALLOC;
+#ifdef ET_PROBE_FUSED_OCC
+        if (smem_wave < 84u * 1024u) smem_wave = 84u * 1024u;  // more than half the LDS: one workgroup per CU, as beside a 47 KiB tree table
+#endif
         const uint32_t n_units = (n_blocks * 4 + WAVES - 1) / WAVES;
         ET_LAUNCH_TIMED(k_dec_write_wave<WAVES>, dim3(decode_grid(k_dec_write_wave<WAVES>, smem_wave, n_units, true, 64 * WAVES)), dim3(64 * WAVES), smem_wave, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, void_flags, n_subs, chain_max_len);
         return;

@@ -526,7 +526,10 @@ void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes,
                     uint32_t max_trips, const uint32_t *worklist, const uint32_t *n_work, KernelEvents ev, uint32_t *blk_pub, uint32_t mode, uint32_t *exit_bits) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     const uint32_t entries = tw_table_entries(n_int);
-    const size_t smem = static_cast<size_t>(entries) * 2;
+    size_t smem = static_cast<size_t>(entries) * 2;
+#ifdef ET_PROBE_FUSED_OCC
+    if (smem < 84u * 1024u) smem = 84u * 1024u;
+#endif
     // workgroups of 8 wavefronts, as many per CU as the table leaves room for in the LDS, at most 3 (<= 80 VGPRs: 6
     // wavefronts per SIMD); a table that leaves room for one workgroup only gets one of 16 wavefronts
     static thread_local int seen_dev = -1, cus = 256;
@@ -545,6 +548,10 @@ void launch_tw_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes,
     uint32_t waves = (4u * ET_TW_WAVES_PER_EU + per_cu - 1) / per_cu;
     if (waves * per_cu > 4u * ET_TW_WAVES_PER_EU) --waves;
     waves = waves > 16 ? 16 : waves;
+#ifdef ET_PROBE_FUSED_OCC  // (round-4 probe: the sweep at the occupancy of a kernel that also holds the write pass's tables and stages)
+    per_cu = 1;
+    waves = ET_PROBE_FUSED_OCC;
+#endif
     const uint32_t threads = waves * 64;
     uint32_t grid = static_cast<uint32_t>(cus) * per_cu;
     if (grid > (n_blocks + waves - 1) / waves) grid = (n_blocks + waves - 1) / waves;

@@ -131,7 +131,7 @@ def main():
                     head = stream[:8192]
                     off, ln = groups[r].decode_window(head, comp.numel())
                     window = comp[off : off + ln].clone() if ln else None
-                    torch.cuda.synchronize()  # (the clone runs on torch's stream, the group's calls on its context's own)
+                    # (no synchronize: the clone runs on torch's current stream, and so do the group's calls -- codec.Context follows it)
                     mine, first = groups[r].decode_begin(head, comp.numel(), window, off)
                     m = groups[r].decode_write(outs[r]) if mine else 0
                     assert m == mine

@@ -1160,3 +1160,38 @@ def test_write_by_quarters_windows_ragged_ends_and_clamps(ctx):
     out = torch.empty(len(full) + 64, dtype=torch.uint8, device="cuda")
     m = ctx.decode_device(comp, out)
     assert m == len(full) and out[:m].cpu().numpy().tobytes() == full
+
+
+def test_device_calls_are_ordered_on_torchs_current_stream():
+    """A fresh Context, no use_torch_stream(), no synchronize anywhere: the input is still being PRODUCED on torch's stream (a
+    chain of large element-wise kernels) when encode_device / decode_device are called, on the default stream and inside a
+    torch.cuda.stream(...) block -- the calls run on whatever stream is current, so they see finished tensors and the decode
+    sees the finished image (the soak of round 3 raced here: a context used to sit on a private stream unless told otherwise)."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    host = corpus.text_like(24 << 20, 77)
+    want = O.encode(host.tobytes())
+    side = torch.cuda.Stream()
+    for stream in (None, side):
+        c = E.Context(0)  # fresh: default behaviour
+        try:
+            base = torch.from_numpy(host).cuda()
+            enc = torch.zeros(E.encode_bound(host.size) + 64, dtype=torch.uint8, device="cuda")
+            dec = torch.zeros(host.size + 64, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+                text = base ^ 0x5A  # a few ms of kernels on the current stream; the last one restores the text
+                for _ in range(40):
+                    text = (text ^ 0xFF) ^ 0xFF
+                text = text ^ 0x5A
+                n = c.encode_device(text, enc)  # no synchronize in front of it
+                m = c.decode_device(enc[4:n], dec)  # nor here
+                got = enc[:n].clone()
+            torch.cuda.synchronize()
+            assert got.cpu().numpy().tobytes() == want
+            assert m == host.size and dec[:m].cpu().numpy().tobytes() == host.tobytes()
+        finally:
+            c.close()

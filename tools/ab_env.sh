@@ -11,6 +11,6 @@ import json,sys
 v=sys.argv[1]
 d=json.load(open(f"gpurun_out/ab_{v}.json"))
 p=d["phase_ms"]; w=d.get("workloads",{}).get("enwik-like",{}); q=w.get("phase_ms",{})
-print(f"{v:12s} value {d['value']:7.1f} cold {d.get('value_cold',0):7.1f} | hist {p['hist']:.4f} scan {p['enc_scan']:.4f} body {p['enc_body']:.4f} enc {p['enc_total']:.4f} | sync {p['dec_sync_first']:.4f} dbody {p['dec_body']:.4f} dec {p['dec_total']:.4f}" + (f" | enwik rt {w.get('round_trip_GBps',0):.1f} dec {q.get('dec_total',0):.4f} enc {q.get('enc_total',0):.4f}" if w else ""))
+print(f"{v:12s} value {d.get('value', d.get('value_unverified', 0)):7.1f} cold {d.get('value_cold',0):7.1f} | hist {p['hist']:.4f} scan {p['enc_scan']:.4f} body {p['enc_body']:.4f} enc {p['enc_total']:.4f} | sync {p['dec_sync_first']:.4f} dbody {p['dec_body']:.4f} dec {p['dec_total']:.4f}" + (f" | enwik rt {w.get('round_trip_GBps',0):.1f} dec {q.get('dec_total',0):.4f} enc {q.get('enc_total',0):.4f}" if w else ""))
 PY
 done
