@@ -264,6 +264,7 @@ int run_sharded(const Options &opt, int in_fd, int out_fd, size_t *in_size, size
             et_group *grp = grps[r];
             void *d_in = nullptr, *d_out = nullptr;
             auto bail = [&](int rc, const char *what, bool local) {
+                if (out.rc != ET_OK && out.local) return;  // (this rank's own first cause stays: what the exchanges relay afterwards is its echo)
                 out.rc = rc;
                 out.local = local;
                 out.err = std::string(what) + ": " + (*et_group_last_error(grp) ? et_group_last_error(grp) : et_last_error(ctx));
@@ -271,10 +272,16 @@ int run_sharded(const Options &opt, int in_fd, int out_fd, size_t *in_size, size
             (void)hipSetDevice(r % n_dev);
             int rc = ET_OK;
             bool ok = true;
+            // (tests: ET_CLI_TEST_FAIL_RANK=r makes rank r's own preparation fail as an unreadable input range would)
+            static const int fail_rank = [] { const char *e = std::getenv("ET_CLI_TEST_FAIL_RANK"); return e ? std::atoi(e) : -1; }();
+            if (r == fail_rank) {
+                bail(ET_ERR_IO, "reading the input", true);
+                ok = false;
+            }
             if (compress) {
                 const size_t lo = file_size * r / world, hi = file_size * (r + 1) / world, n = hi - lo;
                 const size_t cap = et_encode_bound(n);
-                if (hipMalloc(&d_in, n + 16) != hipSuccess || hipMalloc(&d_out, cap + 16) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc", true); ok = false; }
+                if (ok && (hipMalloc(&d_in, n + 16) != hipSuccess || hipMalloc(&d_out, cap + 16) != hipSuccess)) { bail(ET_ERR_NOMEM, "hipMalloc", true); ok = false; }
                 if (ok && (rc = et_fd_to_device(ctx, in_fd, lo, n, d_in)) != ET_OK) { bail(rc, "reading the input", true); ok = false; }
                 out.in_bytes = n;
                 et_shard_info info{};
@@ -296,7 +303,7 @@ int run_sharded(const Options &opt, int in_fd, int out_fd, size_t *in_size, size
                 // this rank's window of the stream: its 8 KiB-block range with 16 bytes on either side -- not the file
                 const size_t len = file_size - 4;
                 uint64_t w_off = 0, w_len = 0;
-                if ((rc = et_decode_shard_window(head.data(), head.size(), len, r, world, &w_off, &w_len)) != ET_OK) { bail(rc, "header", true); ok = false; }
+                if (ok && (rc = et_decode_shard_window(head.data(), head.size(), len, r, world, &w_off, &w_len)) != ET_OK) { bail(rc, "header", true); ok = false; }
                 if (ok && w_len && hipMalloc(&d_in, w_len + 32) != hipSuccess) { bail(ET_ERR_NOMEM, "hipMalloc", true); ok = false; }
                 if (ok && w_len && (rc = et_fd_to_device(ctx, in_fd, 4 + w_off, w_len, d_in)) != ET_OK) { bail(rc, "reading the input", true); ok = false; }
                 out.in_bytes = ok ? static_cast<size_t>(w_len) : 0;

@@ -2312,8 +2312,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
         walk_write_chain<2>(cw, smem8, W, start, my_lo, (win_), (win_hi_), stage_off);                     \
     }
 // (the wavefront's own LDS stores, then its own loads: in order, no barrier)
+// (WV_LDS_ORDER: the walk stores bytes through integer-made LDS addresses, the copy-out reads them through `stage`, and lanes read
+// what OTHER lanes of the wavefront stored: a wavefront-scope release / acquire pair around a wave barrier says so to the compiler --
+// no instruction comes of it, the LDS itself keeps a wavefront's accesses in order -- in front of the reads and again in front of
+// the next walk's stores)
+#define WV_LDS_ORDER()                                          \
+    {                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    }
 #define WV_WINDOW_STORE(win_, win_hi_)                                                                     \
     {                                                                                                      \
+        WV_LDS_ORDER()                                                                                     \
         const uint32_t lo_valid = max((win_), phase); /* first stage position holding a symbol in this window */ \
         for (uint32_t g = (win_) + lane * 16; g < (win_hi_); g += 64 * 16) {                               \
             if (g >= lo_valid && g + 16 <= (win_hi_)) {                                                    \
@@ -2327,6 +2338,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
         const uint32_t pos = (lane < 16 ? head : tail) + (lane & 15u);                                     \
         const bool partial = lane < 16 ? (lo_valid & 15u) != 0 : ((win_hi_) & 15u) != 0; /* (one chunk for both: its bytes are stored twice) */ \
         if (lane < 32 && partial && pos >= lo_valid && pos < (win_hi_)) out_base[pos] = stage[pos - (win_)]; \
+        WV_LDS_ORDER()                                                                                     \
     }
             uint32_t win = 0;
             if (span) {
@@ -2340,6 +2352,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
             WV_TAKE()
             if (span) WV_WINDOW_STORE(win, span)
 #undef WV_WINDOW_STORE
+#undef WV_LDS_ORDER
 #undef WV_WINDOW_WALK
         }
 #undef WV_TAKE

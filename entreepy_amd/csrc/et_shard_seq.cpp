@@ -215,7 +215,7 @@ extern "C" int et_seam_word(const uint64_t *start_bits, uint32_t world, uint32_t
 extern "C" int et_encode_sharded(et_group *g, const void *d_text, size_t n, void *d_out, size_t cap, et_shard_info *info) {
     if (!g || !info) return ET_ERR_ARG;
     g->err.clear();
-    g->have_plan = g->seams_merged = false;
+    g->have_plan = g->seams_merged = g->seams_exchanged = false;
     const int world = g->world, r = g->rank;
     // (1) what can be checked here, then the local histogram -- whatever comes of it, the exchange is made
     int st = g->poison;
@@ -296,7 +296,13 @@ extern "C" int et_encode_sharded(et_group *g, const void *d_text, size_t n, void
 // -------------------------------------------------------------------------------------------------------------------
 extern "C" int et_shard_merge_seams(et_group *g, void *d_out) {
     if (!g) return ET_ERR_ARG;
-    if (g->have_plan && g->seams_merged) return ET_OK;  // (the same on every rank: they make the same calls)
+    // A repeated call makes no exchange -- on ANY rank: what decides is whether this plan's exchange has been made, which all
+    // ranks know alike, not whether this rank's own patch behind it went through (a rank whose patch failed is poisoned and
+    // says so here; deciding by its own success it would walk into an all-gather that nobody else joins).
+    if (g->have_plan && g->seams_exchanged) {
+        if (g->seams_merged) return ET_OK;
+        return fail(g, g->poison != ET_OK ? g->poison : ET_ERR_HIP, "the seam word was never patched: the group failed in an earlier call");
+    }
     g->err.clear();
     const int world = g->world, r = g->rank;
     const et_shard_info &o = g->info;
@@ -324,6 +330,7 @@ extern "C" int et_shard_merge_seams(et_group *g, void *d_out) {
     int rc = gather(g, &mine, rows.data(), sizeof mine);
     if (rc != ET_OK) return rc;
     if ((rc = settle(g, rows.data(), "et_shard_merge_seams")) != ET_OK) return rc;
+    g->seams_exchanged = true;
     std::vector<uint32_t> all(2 * static_cast<size_t>(world));
     for (int q = 0; q < world; ++q) {
         all[2 * q] = rows[q].first;

@@ -113,6 +113,7 @@ struct et_group {
 
     // the plan of the last et_encode_sharded
     bool have_plan = false, seams_merged = false;
+    bool seams_exchanged = false;  // the merge's exchange of this plan has been made (the same on every rank, whatever a rank's own patch did afterwards)
     et_codebook cb = {};
     std::vector<uint64_t> starts;  // world + 1 file bit offsets
     std::vector<uint8_t> header;

@@ -12,7 +12,11 @@
 #include "et_oracle.h"
 #include "et_shard_seq.h"
 
+#include <atomic>
+
 namespace {
+
+std::atomic<int> g_fail_patches{0};  // tests: the next so many patch_word calls fail (et_cpu_fail_next_patches)
 
 struct OracleBackend : et_shard::Backend {
     std::string err;
@@ -85,6 +89,7 @@ struct OracleBackend : et_shard::Backend {
         return ET_OK;
     }
     int patch_word(void *d_out, uint64_t word, uint32_t value) override {
+        if (g_fail_patches.load() > 0 && g_fail_patches.fetch_sub(1) > 0) return bad(ET_ERR_HIP, "patch_word: injected failure");
         std::memcpy(static_cast<uint8_t *>(d_out) + word * 4, &value, 4);
         return ET_OK;
     }
@@ -213,6 +218,9 @@ struct OracleBackend : et_shard::Backend {
 };
 
 }  // namespace
+
+// Test hook: the next n patch_word calls of any backend in this process fail with ET_ERR_HIP (a failure BEHIND the merge's exchange).
+extern "C" void et_cpu_fail_next_patches(int n) { g_fail_patches.store(n); }
 
 // The product's et_group_create with a stand-in where the et_ctx would be (ctx is ignored).
 extern "C" int et_group_create(et_ctx *, int rank, int world, et_allgather_fn allgather, void *user, et_group **out) {

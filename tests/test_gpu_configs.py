@@ -445,6 +445,23 @@ def test_cli_gpus_shards_one_file(tmp_path, res_files):
     assert et.read_bytes() == O.encode(res_files["test.txt"])
 
 
+def test_cli_gpus_a_ranks_own_failure_decides_message_and_exit_status(tmp_path, res_files):
+    """`entreepy --gpus 3` with one rank's preparation failing (ET_CLI_TEST_FAIL_RANK: as an unreadable input range would):
+    that rank still makes its group calls with nothing to contribute, its peers hear ET_ERR_ARG through the exchange rows --
+    and what the process reports is the failing rank's OWN cause (an I/O error reading the input), not the echo; nobody hangs,
+    for compress and for decompress."""
+    src = tmp_path / "t.txt"
+    src.write_bytes(res_files["a_midsummer_nights_dream.txt"] * 3)
+    et = tmp_path / "t.et"
+    r = subprocess.run([EXE, "--gpus", "3", "c", str(src), "-o", str(et)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for mode, args in (("c", [str(src), "-o", str(tmp_path / "x.et")]), ("d", [str(et), "-o", str(tmp_path / "x.txt")])):
+        for rank in (0, 1, 2):
+            r = subprocess.run([EXE, "--gpus", "3", mode] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, ET_CLI_TEST_FAIL_RANK=str(rank)))
+            assert r.returncode == 1, (mode, rank, r.stderr)
+            assert "reading the input" in r.stderr and "file read/write error" in r.stderr, (mode, rank, r.stderr)
+
+
 def test_cli_debug_prefix_collision_check(tmp_path):
     """-d also runs the reference's prefix self-check (encode.zig:221-247; the loop is unit-tested on a
     crafted table in test_host_logic.py).  A Huffman table never trips it -- not even one the u32 truncation

@@ -282,6 +282,41 @@ def test_merge_failure_on_one_rank_reaches_all():
     _all_failed_with(res, N.ET_ERR_RCCL)
 
 
+def test_patch_failure_behind_the_merge_exchange_strands_nobody():
+    """A rank whose seam-word patch fails AFTER the merge's exchange is poisoned alone (its peers merged fine).  When all
+    ranks then call merge again, nobody makes an exchange: the peers return ET_OK, the failed rank its error -- it used to
+    decide by its own success, walk into the all-gather alone and hang."""
+    from tests.support import shard_cpu_lib
+    from entreepy_amd import _native as N
+    from entreepy_amd.codec import EntreepyError
+
+    world = 3
+    _, texts, encs = _shards(world)
+    x = ThreadGather(world)
+    groups = [_cpu_group(r, world, x.of(r)) for r in range(world)]
+    res = _run_ranks(world, lambda r: groups[r].encode_sharded(texts[r], encs[r]))
+    assert all(k == "ok" for k, _ in res), res
+    lib = shard_cpu_lib()
+    lib.et_cpu_fail_next_patches(1)  # whichever rank patches first
+    try:
+        res = _run_ranks(world, lambda r: groups[r].merge_seams(encs[r]))
+    finally:
+        lib.et_cpu_fail_next_patches(0)
+    failed = [r for r, (k, _) in enumerate(res) if k == "err"]
+    assert len(failed) == 1 and res[failed[0]][1].status == N.ET_ERR_HIP, res
+    calls = list(x.calls)
+    res = _run_ranks(world, lambda r: groups[r].merge_seams(encs[r]))  # (hangs here without the fix: _run_ranks times out)
+    assert x.calls == calls, "a repeated merge makes no exchange on any rank"
+    for r, (k, e) in enumerate(res):
+        if r in failed:
+            assert k == "err" and isinstance(e, EntreepyError) and e.status == N.ET_ERR_HIP
+        else:
+            assert k == "ok"
+    # a new encode clears the plan; the poisoned rank carries its status through the exchange and everybody hears of it
+    res = _run_ranks(world, lambda r: groups[r].encode_sharded(texts[r], encs[r]))
+    _all_failed_with(res, N.ET_ERR_HIP)
+
+
 @pytest.mark.parametrize("kind", ["text", "flat"])
 def test_cold_decode_failure_on_one_rank_reaches_all(kind):
     """world 3, cold decode: one rank's output buffer is too small for its share (known to all from the rows), one
