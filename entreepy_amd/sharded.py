@@ -166,12 +166,17 @@ class ShardedCodec:
     DECODE_SHARD = ("shard ranges with the encode's offsets: every rank decodes the bits of its own shard with the code table and start bit of "
                     "the encode step that produced them (an in-memory pipeline; no header hand-over or parse, no exchange)")
 
-    def decode_shard(self, enc, layout, dec):
+    def decode_shard(self, enc, layout, dec, as_shard=False):
         """Decode this rank's piece back into dec; returns the symbol count.  With one
         GPU this is the reference's decode(file[4..]) (header parsed from the stream);
         with several, every rank decodes its own bit range [S_r, S_{r+1}) using the
-        offsets the encode step produced (an in-memory pipeline, not a cold .et read)."""
+        offsets the encode step produced (an in-memory pipeline, not a cold .et read).
+        as_shard: one GPU, decoded the way the ranks of a group decode their shards -- the body with the encode's own
+        code table, no header hand-over (what bench.py compares an N > 1 step with)."""
         ctx = self.ctx
+        if layout["single"] and as_shard:
+            hdr = layout["header_len"]
+            return ctx.decode_body_device(ctx.last_codebook(), enc[hdr : layout["et_len"]], layout["n"], dec, 0)
         if layout["single"]:
             return ctx.decode_device(enc, dec, 4, layout["et_len"] - 4)  # main.zig:204: text_in[4..]
         start = layout["local_start_bit"]

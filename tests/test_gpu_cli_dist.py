@@ -462,5 +462,24 @@ def test_bench_starts_its_own_ranks():
     assert abs(d["value"] - 2 * (16 << 20) / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
     for k in ("exchange_ms", "seam_ms", "concat_ms", "scaling_efficiency", "exchange"):
         assert k in d, k
-    assert abs(d["scaling_efficiency"] - d["value"] / 200.0) < 1e-3
+    assert abs(d["scaling_efficiency"] - d["value"] / 200.0) < 1e-3 and d["scaling_efficiency_against"] == "--ref-value"
+    assert d["config"]["decode"].startswith("shard ranges with the encode's offsets")
+    # what an efficiency is computed from when nobody hands in --ref-value: the same step on one GPU per rank, this run; and the
+    # cold decode of the concatenated image by the ranks, beside it
+    assert d["value_n1_same_step"] > 0 and abs(d["value_n1_same_step"] - (16 << 20) / (d["ms_per_step_n1_same_step"] * 1e-3) / 1e9) < 0.01 * d["value_n1_same_step"]
+    assert isinstance(d["decode_cold_sharded_ms"], float) and d["decode_cold_sharded_ms"] > 0, d["decode_cold_sharded_ms"]
+
+
+def test_bench_n1_shard_style_decode():
+    """`bench.py --decode shard` at N = 1: the step an N > 1 value is comparable with (the body decoded with the encode's own
+    code table, no header hand-over); the line says which decode it timed."""
+    import json
+    import sys
+
+    env = dict(os.environ, ET_BENCH_BYTES=str(16 << 20))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--decode", "shard", "--no-cpu-baseline", "--no-extra-workloads"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["verified"] is True
     assert d["config"]["decode"].startswith("shard ranges with the encode's offsets")
