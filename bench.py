@@ -187,8 +187,11 @@ def measure_stream(torch, ctx, pipe, text, enc, dec, reps, lead, decode=True, ve
         out["decode_GBps"] = round(n / (p["dec_total"] * 1e-3) / 1e9, 2)
         out["decode_hbm_frac"] = round((n + packed) / (p["dec_total"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         out["kernels_only_round_trip_GBps"] = round(n / ((p["enc_total"] + p["dec_total"]) * 1e-3) / 1e9, 2)  # n / (enc_total + dec_total): begin of K1 .. end of K4 plus begin of D1 .. end of D3, instrumented steps
-        out["decode_path"] = ("k_row_sync" if td.get("row_sync") else "exhaustive maps (k_dec_maps_reg / k_dec_compose / k_dec_chain / k_dec_resolve_reg)" if td["exhaustive_sync"]
-                              else ("k_tw_sync" if td["tree_walk_sync"] else "k_dec_sync_reg2")) + " + " + ("k_dec_write_wave" if td["chained_write"] else "k_dec_write_reg")
+        if td.get("row_sync"):
+            out["decode_path"] = "k_row_sync + k_row_write" if os.environ.get("ET_NO_ROW_WRITE") != "1" else "k_row_sync + k_dec_write_wave"
+        else:
+            out["decode_path"] = ("exhaustive maps (k_dec_maps_reg / k_dec_compose / k_dec_chain / k_dec_resolve_reg)" if td["exhaustive_sync"]
+                                  else ("k_tw_sync" if td["tree_walk_sync"] else "k_dec_sync_reg2")) + " + " + ("k_dec_write_wave" if td["chained_write"] else "k_dec_write_reg")
         out["verified"] = ok
     return out
 

@@ -1085,6 +1085,13 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     };
     auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
         // speculative: the kernel itself looks at the sweeps' flags and does nothing if the state is not final
+        static const bool row_write_off = [] { const char *e = std::getenv("ET_NO_ROW_WRITE"); return e && e[0] == '1'; }();  // (A/B: the chained-table write on a row code's stream)
+        if (row_sync && !row_write_off) {  // by rows (et_rowsync.h): no table chain, no bank conflicts between the lanes' regions
+            const et::KernelEvents ev = timed_body(ctx, EV_DEC + 2, EV_DEC + 3);
+            et::launch_row_write(ctx->stream, words, n_bytes, first_bit, n_subs, row_code, cb, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), ev.start, ev.stop);
+            ET_HIP(hipGetLastError());
+            return ET_OK;
+        }
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
                              write_ticket_zero, speculative ? flag : nullptr, timed_body(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain, cb->max_length);
         write_ticket_zero = false;
@@ -1212,7 +1219,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm_dec = et_timings{};
         ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
         ctx->tm_dec.sync_iters = iters;
-        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u);
+        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u);  // (row_sync: k_row_sync, and k_row_write unless ET_NO_ROW_WRITE)
         ctx->pend_dec = true;
         ctx->pend_dec_first = iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2);
         ctx->last_kind = 1;

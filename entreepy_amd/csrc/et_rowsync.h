@@ -46,5 +46,11 @@ size_t row_sync_scratch_bytes(uint32_t n_blocks);
 void launch_row_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, RowCode rc, void *scratch, uint32_t *fault,
                      uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count);
 
+// The write pass for such a stream, by rows (k_row_write): sub_state as launch_row_sync leaves it, blk_off from the scan of
+// blk_count; at most n_symbols symbols to out (16-byte aligned).  ev_start / ev_stop: events the dispatch carries (may be null).
+void launch_row_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, RowCode rc, const et_codebook *cb,
+                      const uint32_t *sub_state, const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, hipEvent_t ev_start = nullptr,
+                      hipEvent_t ev_stop = nullptr);
+
 }  // namespace et
 #endif

@@ -22,6 +22,7 @@
 // taken by workgroups that are running.)
 #include "et_rowsync.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 namespace et {
@@ -311,6 +312,173 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+//   decode.zig:186 -> k_row_write: the symbols of a row code's stream, written by rows.
+//
+// The general write pass (k_dec_write_wave, et_kernels.hip) looks codewords up in chained tables, one dependent LDS round trip
+// per step, and stores a byte per symbol into its wavefront's stage.  On these streams every subsequence yields 32..37 symbols, so
+// the 64 lanes' regions of the stage begin 32 bytes apart: lanes l and l + 4 store to the same LDS bank at every step -- 8-way
+// conflicts on every byte store, 82 % of that kernel's LDS cycles (r04 PMC), 4.5 ms per 4 GiB.  Here a lane steps down the 32 rows
+// of its subsequence: the 8 bits at (row, column) come out of registers (v_bfe_u32 at 8 - column), "is it a 7-bit code" is a compare
+// with 2t that only the column depends on (the symbol lookup -- a 256-byte table in LDS -- is off that chain), and the stage is
+// PADDED by 4 bytes per 128: position p lies at p + 4 (p >> 7), which puts the lanes' stores on different banks and keeps every
+// 16-byte chunk of the output in one piece.
+namespace {
+
+constexpr uint32_t RWR_STAGE_LOGICAL = 64 * 37 + 16;                                 // symbols a wavefront can yield, + the phase of its first
+constexpr uint32_t RWR_STAGE = ((RWR_STAGE_LOGICAL + 4 * (RWR_STAGE_LOGICAL >> 7) + 4) + 127) & ~127u;  // with the pads, rounded
+
+struct RowLut {
+    uint8_t sym[256];  // the symbol whose codeword the 8 bits begin with
+};
+
+__device__ __forceinline__ uint32_t rwr_scan(uint32_t x) {  // inclusive prefix sum over the wavefront (DPP)
+#define RWR_DPP(ctrl_, mask_) x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), ctrl_, mask_, 0xf, false))
+    RWR_DPP(0x111, 0xf);
+    RWR_DPP(0x112, 0xf);
+    RWR_DPP(0x114, 0xf);
+    RWR_DPP(0x118, 0xf);
+    RWR_DPP(0x142, 0xa);
+    RWR_DPP(0x143, 0xc);
+#undef RWR_DPP
+    return x;
+}
+
+typedef __attribute__((address_space(3))) uint8_t rwr_lds_u8;
+typedef __attribute__((address_space(3))) uint32_t rwr_lds_u32;
+
+}  // namespace
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_row_write(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks, uint64_t n_subs, uint32_t first_bit,
+                                                         uint32_t code_t, const RowLut lut, const uint32_t *__restrict__ sub_state,
+                                                         const unsigned long long *__restrict__ blk_off, uint64_t n_symbols, uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(128))) uint8_t smem[256 + WAVES * RWR_STAGE];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t i = tid; i < 64; i += 64 * WAVES) reinterpret_cast<uint32_t *>(smem)[i] = reinterpret_cast<const uint32_t *>(lut.sym)[i];
+    __syncthreads();
+    const uint32_t lds_lut = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((rwr_lds_u8 *)smem));
+    const uint32_t lds_stage = lds_lut + 256u + wv * RWR_STAGE;  // this wavefront's stage: LDS address of position 0
+    const uint64_t n_bits = n_bytes * 8, n_words_full = n_bytes / 4;
+    const uint32_t two_t = 2 * code_t;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(words);
+    // symbol at stage position p lies at LDS address lds_stage + p + 4 (p >> 7)
+#define RWR_ADDR(p_) (lds_stage + (p_) + (((p_) >> 7) << 2))
+    const uint32_t stride = gridDim.x * WAVES, n_units = n_blocks * 4;
+    for (uint32_t u = blockIdx.x * WAVES + wv; u < n_units; u += stride) {
+        const uint64_t b = u >> 2;
+        const uint32_t quarter = u & 3u;
+        const uint64_t sub_g = b * 256 + quarter * 64 + lane;
+        const bool live = sub_g < n_subs;
+        // where the wavefront's output begins: the block's offset + the quarters before this one (the same lane of each)
+        uint32_t before = 0, st = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint64_t sg = b * 256 + q * 64 + lane;
+            const uint32_t v = (q <= quarter && sg < n_subs) ? sub_state[sg] : 0u;
+            if (q == quarter) st = v;
+            if (q < quarter) before += v >> 16;
+        }
+        const unsigned long long o0 = blk_off[b];
+        before = __builtin_amdgcn_readlane(rwr_scan(before), 63);
+        const uint32_t count = live ? st >> 16 : 0u;
+        const uint32_t inc = rwr_scan(count);
+        const uint32_t wave_total = __builtin_amdgcn_readlane(inc, 63), my_off = inc - count;
+        const uint64_t ow = o0 + before;
+        const bool nothing = o0 >= n_symbols || ow >= n_symbols || wave_total == 0;  // (pad bits decoded past the declared length)
+        uint64_t o1 = ow + wave_total;
+        if (o1 > n_symbols) o1 = n_symbols;
+        const uint32_t n_out = nothing ? 0u : static_cast<uint32_t>(o1 - ow);
+        const uint32_t phase = static_cast<uint32_t>(ow & 15);
+        const uint32_t span = nothing ? 0u : phase + n_out;
+        uint8_t *out_base = out + (ow - phase);
+        if (nothing) continue;  // (wavefront-uniform)
+        const uint32_t my_lo = phase + my_off;
+        const uint64_t sub_end = (sub_g + 1) * 256;
+        const bool slow = live && count && (sub_g == 0 || sub_end + 8 > n_bits);
+        const bool fast = live && count && !slow;
+        if (fast) {
+            const bool interior = (b + 1) * 2048 + 1 <= n_words_full;  // wavefront-uniform
+            uint32_t X[9];
+            if (interior) {
+                const uint32_t *src = words + sub_g * 8;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) X[j] = __builtin_bswap32(src[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) X[j] = __builtin_bswap32(rs_load_guarded(words, sub_g * 8 + j, n_bytes));
+            }
+            uint32_t sh = 8u - (st & 7u);  // 8 - column: how far the codeword's 8 bits lie above the NEXT row's first bit
+            uint32_t pos = my_lo;          // stage position of the current row's first symbol, less the row's number
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int k = j >> 2, i = j & 3;
+                // the 16 bits of rows j, j + 1 are bits [16 - 8 i, 32 - 8 i) of X[k] (i < 3) or the low 16 of (X[k] : X[k + 1]) >> 24
+                uint32_t w8;
+                if (i < 3) w8 = __builtin_amdgcn_ubfe(X[k], sh + (16 - 8 * i), 8);
+                else w8 = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(X[k], X[k + 1], 24), sh, 8);
+                const uint32_t sym = *reinterpret_cast<const rwr_lds_u8 *>(static_cast<uintptr_t>(lds_lut + w8));
+                const uint32_t p = pos + j;
+                *reinterpret_cast<rwr_lds_u8 *>(static_cast<uintptr_t>(RWR_ADDR(p))) = static_cast<uint8_t>(sym);
+                sh += w8 < two_t ? 1u : 0u;  // a 7-bit code: the next one begins a column further left
+                if (__any(sh == 9)) {        // ... from column 0 that is column 7 of the SAME row: one more codeword in it
+                    if (sh == 9) {
+                        uint32_t h;
+                        if (i < 3) h = X[k] >> (16 - 8 * i);
+                        else h = __builtin_amdgcn_alignbit(X[k], X[k + 1], 24);
+                        const uint32_t w7 = (h >> 1) & 0xffu;
+                        const uint32_t sym2 = *reinterpret_cast<const rwr_lds_u8 *>(static_cast<uintptr_t>(lds_lut + w7));
+                        ++pos;
+                        const uint32_t p2 = pos + j;
+                        *reinterpret_cast<rwr_lds_u8 *>(static_cast<uintptr_t>(RWR_ADDR(p2))) = static_cast<uint8_t>(sym2);
+                        sh = w7 < two_t ? 2u : 1u;
+                    }
+                }
+            }
+        } else if (slow) {
+            // the stream's first subsequence and the one or two it ends in: one codeword at a time, as many as were counted
+            uint64_t at = sub_g == 0 ? first_bit : sub_g * 256 + (st & 31u);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint64_t byte = at >> 3;
+                const uint32_t s8 = static_cast<uint32_t>(at & 7);
+                const uint32_t b0 = bytes[byte], b1 = byte + 1 < n_bytes ? bytes[byte + 1] : 0u;
+                const uint32_t w8 = (((b0 << 8) | b1) >> (8 - s8)) & 0xffu;
+                const uint32_t p = my_lo + k;
+                *reinterpret_cast<rwr_lds_u8 *>(static_cast<uintptr_t>(RWR_ADDR(p))) = smem[w8];
+                at += w8 < two_t ? 7 : 8;
+            }
+        }
+        // (the wavefront's own LDS stores, then its own loads: in order; the fences say so to the compiler, no instruction comes of them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the stage leaves as 16-byte chunks (a chunk never straddles a pad), the two chunks shared with the neighbours byte by byte
+        const uint32_t lo_valid = phase;
+        for (uint32_t g = lane * 16; g < span; g += 64 * 16) {
+            if (g >= lo_valid && g + 16 <= span) {
+                const uint32_t a = RWR_ADDR(g);
+                typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+                u32x4_nt v;
+                v.x = *reinterpret_cast<const rwr_lds_u32 *>(static_cast<uintptr_t>(a));
+                v.y = *reinterpret_cast<const rwr_lds_u32 *>(static_cast<uintptr_t>(a + 4));
+                v.z = *reinterpret_cast<const rwr_lds_u32 *>(static_cast<uintptr_t>(a + 8));
+                v.w = *reinterpret_cast<const rwr_lds_u32 *>(static_cast<uintptr_t>(a + 12));
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_nt *>(out_base + g));
+            }
+        }
+        {
+            const uint32_t head = lo_valid & ~15u, tail = span & ~15u;
+            const uint32_t p = (lane < 16 ? head : tail) + (lane & 15u);
+            const bool partial = lane < 16 ? (lo_valid & 15u) != 0 : (span & 15u) != 0;
+            if (lane < 32 && partial && p >= lo_valid && p < span) out_base[p] = *reinterpret_cast<const rwr_lds_u8 *>(static_cast<uintptr_t>(RWR_ADDR(p)));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#undef RWR_ADDR
+}
+
 size_t row_sync_scratch_bytes(uint32_t n_blocks) {
     const size_t n_chunks = (static_cast<size_t>(n_blocks) + RS_CH - 1) / RS_CH;
     return n_chunks * sizeof(unsigned long long) + 64;
@@ -335,6 +503,35 @@ void launch_row_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
     if (grid > n_chunks) grid = n_chunks;
     hipLaunchKernelGGL(k_row_sync, dim3(grid), dim3(RS_THREADS), 0, stream, words, n_bytes, first_bit, n_subs, n_blocks, n_chunks, rc.t, pub, ticket, fault, sub_state, blk_exit,
                        blk_count);
+}
+
+void launch_row_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, RowCode rc, const et_codebook *cb,
+                      const uint32_t *sub_state, const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    constexpr int WAVES = 8;
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + RS_THREADS - 1) / RS_THREADS);
+    if (!n_blocks) return;
+    RowLut lut = {};
+    for (int s = 0; s < 256; ++s) {  // every 8-bit pattern begins with exactly one codeword (the code is complete)
+        const uint32_t len = cb->length[s];
+        if (len == 7) lut.sym[(cb->data[s] & 0x7fu) << 1] = lut.sym[((cb->data[s] & 0x7fu) << 1) | 1u] = static_cast<uint8_t>(s);
+        else if (len == 8) lut.sym[cb->data[s] & 0xffu] = static_cast<uint8_t>(s);
+    }
+    static thread_local int seen_dev = -1, cus = 256, per_cu = 4;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != seen_dev) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_row_write<WAVES>, 64 * WAVES, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        seen_dev = dev;
+    }
+    const uint32_t n_wg = (n_blocks * 4 + WAVES - 1) / WAVES;
+    uint32_t grid = static_cast<uint32_t>(cus) * static_cast<uint32_t>(per_cu);
+    if (grid > n_wg) grid = n_wg;
+    if (ev_start || ev_stop)
+        hipExtLaunchKernelGGL(k_row_write<WAVES>, dim3(grid), dim3(64 * WAVES), 0, stream, ev_start, ev_stop, 0, words, n_bytes, n_blocks, n_subs, first_bit, rc.t, lut, sub_state, blk_off,
+                              n_symbols, out);
+    else
+        hipLaunchKernelGGL(k_row_write<WAVES>, dim3(grid), dim3(64 * WAVES), 0, stream, words, n_bytes, n_blocks, n_subs, first_bit, rc.t, lut, sub_state, blk_off, n_symbols, out);
 }
 
 }  // namespace et

@@ -189,8 +189,10 @@ def test_large_stream_many_chunks_in_flight(ctx):
         assert m == n and torch.equal(dec[:n], text)
 
 
-def test_fallback_exit_maps_still_decode_these_streams():
-    """ET_NO_ROW_SYNC=1 (a child process: the switch is read once): the same streams through k_dec_maps_reg / k_dec_resolve_reg."""
+@pytest.mark.parametrize("switch", ["ET_NO_ROW_SYNC", "ET_NO_ROW_WRITE"])
+def test_fallback_exit_maps_still_decode_these_streams(switch):
+    """ET_NO_ROW_SYNC=1 (a child process: the switch is read once): the same streams through k_dec_maps_reg / k_dec_resolve_reg
+    and the chained-table write; ET_NO_ROW_WRITE=1: the row walk's synchronisation with the chained-table write behind it."""
     code = (
         "import numpy as np, entreepy_amd as E\n"
         "from tests.test_gpu_rowsync import flat\n"
@@ -201,8 +203,8 @@ def test_fallback_exit_maps_still_decode_these_streams():
         "    et = O.encode(d.tobytes())\n"
         "    assert c.decode(et[4:]) == d.tobytes()\n"
         "    t = c.timings('decode')\n"
-        "    assert t['exhaustive_sync'] and not t['row_sync'], t\n"
+        "    assert t['exhaustive_sync'] and t['row_sync'] == (SWITCH == 'ET_NO_ROW_WRITE'), t\n"
         "print('ok')\n"
-    )
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, ET_NO_ROW_SYNC="1"), timeout=600)
+    ).replace("SWITCH", repr(switch))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **{switch: "1"}), timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
