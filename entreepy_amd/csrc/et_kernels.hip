@@ -155,8 +155,8 @@ __device__ __forceinline__ Chunk load_chunk_in_tile(const uint8_t *__restrict__ 
 // Measured alternative: two 16-bit counters per word (16 KiB, 8 workgroups per CU) is
 // SLOWER (0.30 vs 0.27 ms per GiB): the ceiling is the ds_add rate itself (~8 LDS
 // cycles per wave-instruction, ~4.9 TB/s chip-wide), not occupancy.
-// Counters are u32 (a tile is at most 64 KiB); tile totals go out as u32,
-// workgroup totals as u64.
+// Counters are u32 (a tile is at most 512 KiB = MAX_ROUNDS_PER_TILE rounds of 4 KiB: 2^19 symbols, far inside a u32);
+// tile totals go out as u32, workgroup totals as u64.
 // HIST_BLOCK threads share the workgroup's one set of counters: the 32 KiB of LDS allow only
 // 4 workgroups per CU (a fifth does not fit beside the others' 160 KiB exactly), so 256
 // threads meant 4 wavefronts per SIMD and a latency-bound kernel; 512 threads double the

@@ -26,8 +26,13 @@ def main():
         if trial % 97 == 0:
             ctx.enable_timing(trial % 2 == 0)  # both launch flavours: with and without kernel-carried events
         n = int(rng.integers(20_000, max_bytes))
-        src = int(rng.integers(0, 4))
-        if src == 0:
+        src = int(rng.integers(0, 5))
+        if src == 4:  # flat alphabets of 129 .. 255 symbols: complete codes of 7 and 8 bits -- the row walk (csrc/et_rowsync.hip)
+            k = int(rng.integers(129, 256))
+            vals = (np.arange(k) + int(rng.integers(0, 257 - k))).astype(np.uint8)
+            text = np.tile(vals, n // k + 1)[:n]
+            rng.shuffle(text)
+        elif src == 0:
             text = corpus.text_like(n, seed * 100_000 + trial)
         elif src == 1:
             text = corpus.uniform(n, seed * 100_000 + trial, 1, 1 + int(rng.integers(2, 255)))
