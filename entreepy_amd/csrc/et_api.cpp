@@ -1,5 +1,5 @@
 // et_api.cpp -- the extern "C" boundary of libentreepy_hip.so (include/entreepy_hip.h):
-// context, workspaces, and the orchestration of the kernels in et_kernels.hip.
+// context, workspaces, and the orchestration of the kernels in et_kernels.hip, et_treewalk.hip, et_rowsync.hip and et_kernels_fallback.hip.
 //
 // Encode (replaces encode.zig:25-337):
 //   K1 histogram -> D2H 2 KiB -> host code construction (et_codebook.cpp) -> H2D code

@@ -1,4 +1,4 @@
-// et_kernels.h -- geometry constants and launch wrappers of et_kernels.hip.
+// et_kernels.h -- geometry constants and launch wrappers of et_kernels.hip and et_kernels_fallback.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>

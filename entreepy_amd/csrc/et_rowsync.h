@@ -4,7 +4,7 @@
 // about equal weight the reference's tree (encode.zig:82-138) is complete with depth 8: T codes of 7 bits -- as numbers
 // 0 .. T-1, the two-queue merge hands them out in that order -- and 256 - 2T codes of 8 bits.  Uniform random bytes give 255
 // coded symbols (the reference drops one of 256: SURVEY Q1) and T = 1.  Such a code never re-synchronises, so the tree walk's
-// run-in (et_treewalk.hip) does not apply, and the general answer -- exit maps for every start offset, et_kernels.hip's
+// run-in (et_treewalk.hip) does not apply, and the general answer -- exit maps for every start offset, et_kernels_fallback.hip's
 // k_dec_maps_reg / k_dec_resolve_reg -- walks every subsequence L + 1 = 9 times: 11.3 of the 16 ms a 4 GiB decode took.
 //
 // Here the stream is a matrix of BYTES: a codeword that begins at bit r of byte j ends at bit r of byte j + 1 (8 bits) or at

@@ -53,7 +53,7 @@ __device__ __attribute__((noinline)) uint32_t rs_load_guarded(const uint32_t *__
 
 // One codeword at a time from bit `pos` to the subsequence's end, never past the stream's (the few lanes the stream begins
 // and ends in).  A codeword cut by the stream's end is nobody's; the exit then points at the stream's end, where the next
-// subsequence's walk stops at once (as walk_subsequence's, et_kernels.hip).
+// subsequence's walk stops at once (as walk_subsequence's, et_kernels_fallback.hip).
 // -> exit column | codewords << 8
 __device__ __attribute__((noinline)) uint32_t rs_slow_walk(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t pos, uint64_t sub_end, uint32_t t) {
     const uint64_t n_bits = n_bytes * 8;

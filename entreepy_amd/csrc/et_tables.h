@@ -25,7 +25,7 @@ constexpr uint32_t DEC_SUB_BITS_MAX = 8, DEC_SUB_TABLES_MAX = 16;
 
 // Step table of k_dec_sync_reg / k_dec_sync_reg2 (no symbols, only how far a lookup moves the
 // walk).  The walk state X is one u32: bits 0..15 = G, the position relative to the current
-// register pair (et_kernels.hip walk_steps), bits 16..27 = symbols begun, bits 28..31 junk;
+// register pair (et_kernels_fallback.hip walk_steps), bits 16..27 = symbols begun, bits 28..31 junk;
 // entry = (len_first << 28) + (n << 16) - len_total is simply ADDED to X (n = all the whole
 // codes inside the index, len_first = length of the first one for single steps).  No code
 // inside the index: STEP_ESCAPE = one "symbol" of STEP_ESCAPE_BITS bits, which throws the
@@ -48,7 +48,7 @@ struct HostDecodeTables {
 
 // What the HOST decides about a code table's decode tables -- index widths, which long codes get
 // which second-level table, the order of the long list -- handed to the device, which fills the
-// tables themselves (et_kernels.hip k_build_dec_tables: same entries as the builders below, which
+// tables themselves (et_kernels_fallback.hip k_build_dec_tables: same entries as the builders below, which
 // stay as the reference the device's output is tested against, and as ET_DEC_TABLES_HOST=1).
 struct TablePlan {
     uint32_t data[256];

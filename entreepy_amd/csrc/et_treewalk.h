@@ -2,7 +2,7 @@
 // the host's part (the code table as a tree), launch wrappers.
 //
 // decode.zig:143-203 matches one codeword at a time against a map keyed by code value.  The register-window
-// walks (et_kernels.hip) look whole codewords up greedily, so lanes take different numbers of steps and codes
+// walks (et_kernels_fallback.hip; the write walk of et_kernels.hip) look whole codewords up greedily, so lanes take different numbers of steps and codes
 // longer than the lookup index leave through an escape path -- on a long-tailed alphabet (enwik: ~200
 // symbols, codes past 20 bits) a third of a percent of the symbols escape, which stalls ~70 % of a
 // wavefront's word iterations.  Here the code table is its binary tree (root = a codeword boundary, one

@@ -183,7 +183,7 @@ int et_chain_tables(const et_codebook *cb, uint64_t *table, size_t cap_entries, 
  * re-synchronises (decode.zig:143-203 has no trouble with it; a parallel decoder has).  When the 7-bit codewords are
  * the values 0 .. t-1, which is how encode.zig:82-138 hands them out, a decode synchronises such a stream in one pass by
  * rows (bytes) and columns (bit offsets): csrc/et_rowsync.h.  et_row_code: ET_OK and *t when `cb` is such a code,
- * ET_ERR_UNSUPPORTED otherwise (the exit maps for every start offset then, csrc/et_kernels.hip). */
+ * ET_ERR_UNSUPPORTED otherwise (the exit maps for every start offset then, csrc/et_kernels_fallback.hip). */
 int et_row_code(const et_codebook *cb, uint32_t *t);
 
 /* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */

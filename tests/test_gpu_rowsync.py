@@ -2,7 +2,7 @@
 BASELINE.json calls its worst case (uniform bytes) -- against the oracle, through the C ABI.
 
 What a decode runs is asserted (timings()["row_sync"]), and so is the fallback for the same streams (ET_NO_ROW_SYNC=1 in a
-child process: the exit maps of et_kernels.hip), so both stay pinned."""
+child process: the exit maps of et_kernels_fallback.hip), so both stay pinned."""
 import os
 import subprocess
 import sys
