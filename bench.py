@@ -330,13 +330,13 @@ def main():
     if real is not None and real.size >= (rank + 1) * min(n, real.size // world):
         n = min(n, real.size // world)
         text = torch.from_numpy(real[rank * n : (rank + 1) * n].copy()).to(dev)
-        workload_name = f"enwik9 ($ET_CORPUS_ENWIK9): {n} B per GPU"
+        workload_name = f"enwik9 from $ET_CORPUS_ENWIK9: {n} B per GPU"
         real_sample = real[rank * n : rank * n + min(n, 1 << 30)].copy()  # (the CPU baselines' sample, below)
     else:
         real_sample = None
         text = corpus.text_like_torch(n, 0x5EED0004 + rank, dev)
-        workload_name = (f"text-1G: {n} B per GPU, order-0 samples of a_midsummer_nights_dream.txt's byte distribution "
-                         f"(seed 0x5EED0004+rank)")
+        workload_name = (f"text-1G: {n} B per GPU, order-0 samples of a_midsummer_nights_dream.txt's byte distribution, "
+                         f"seed 0x5EED0004+rank")  # (no parentheses: the driver's parser cuts config.workload at the first one)
     del real
     ctx = E.Context(local)
     ctx.use_torch_stream()
