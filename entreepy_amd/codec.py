@@ -367,7 +367,7 @@ class Context:
         self._bind()
         info = N.RangeInfo()
         _check(N.lib().et_decode_range_resolve(self._h, int(in_start_bit), ctypes.byref(info)), self._h)
-        return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps}
+        return {"start_bit": info.start_bit, "exit_bit": info.exit_bit, "n_symbols": info.n_symbols, "sweeps": info.sweeps, "row_walk": info.reserved == 3}
 
     def decode_range_write(self, max_symbols, out):
         self._bind()

@@ -116,6 +116,11 @@ struct et_ctx {
         // et_decode_range_maps -> et_decode_range_resolve
         bool maps_valid = false, maps_const = false;
         uint32_t map_stride = 0;
+        // a row code's range (et_rowsync.h): maps and resolve are two runs of k_row_sync, the write goes by rows
+        bool row = false;
+        et::RowCode row_code = {};
+        et_codebook row_cb = {};
+        uint32_t first_bit = 0;
     } range;
 };
 
@@ -1251,7 +1256,7 @@ extern "C" int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const vo
     {
         et::TwUpload *h_up = ctx->h_tw_tree[ctx->tw_turn ^= 1];
         if (et::tw_build_tree(cb, &h_up->tree, true) == ET_OK) {
-            rs.valid = false;
+            rs.valid = rs.row = false;
             et::tw_chain_plan(&h_up->tree, &h_up->plan);
             ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));
             ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
@@ -1315,7 +1320,7 @@ extern "C" int et_decode_range_sync(et_ctx *ctx, const et_codebook *cb, const vo
             return ET_OK;
         }
     }
-    rs.tw = false;
+    rs.tw = rs.row = false;
     const bool repair = rs.valid && rs.words == words && rs.n_subs == n_subs && in_start_bit >= 0;
     uint32_t sweeps = 0;
     if (!repair) {
@@ -1391,7 +1396,48 @@ extern "C" int et_decode_range_maps(et_ctx *ctx, const et_codebook *cb, const vo
     if (n_blocks64 > 0x7fffffffull) return fail(ctx, ET_ERR_ARG, "range too large");
     const uint32_t n_blocks = static_cast<uint32_t>(n_blocks64);
     auto &rs = ctx->range;
-    rs.valid = rs.maps_valid = rs.tw = false;
+    rs.valid = rs.maps_valid = rs.tw = rs.row = false;
+    {
+        // Uniform-like bytes (a complete code of 7- and 8-bit codewords): the range's map by rows and columns -- every chunk publishes
+        // its map, the last one composes them (k_row_sync, ROW_MAP_ONLY); the resolve is a second run with the start known.
+        et::RowCode row_code{};
+        static const bool row_off = [] { const char *e = std::getenv("ET_NO_ROW_SYNC"); return e && e[0] == '1'; }();
+        if (!row_off && et::row_code_of(cb, &row_code)) {
+            ET_TRY(ensure(ctx, ctx->sub_state, n_subs * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_exit, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_count, static_cast<size_t>(n_blocks) * sizeof(uint32_t)));
+            ET_TRY(ensure(ctx, ctx->blk_off, (static_cast<size_t>(n_blocks) + 1) * sizeof(uint64_t)));
+            ET_TRY(ensure(ctx, ctx->group_sum, (static_cast<size_t>(n_blocks) / 1024 + 2) * sizeof(uint64_t)));
+            ET_TRY(ensure(ctx, ctx->row_scratch, et::row_sync_scratch_bytes(n_blocks)));
+            ET_TRY(ensure(ctx, ctx->flag, 64));
+            uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
+            ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
+            const bool known = in_start_bit >= 0;
+            const unsigned long long *d_map = nullptr;
+            et::launch_row_sync(ctx->stream, words, n_bytes, known ? static_cast<uint32_t>(in_start_bit) : 0u, n_subs, row_code, ctx->row_scratch.p, flag + 3,
+                                static_cast<uint32_t *>(ctx->sub_state.p), static_cast<uint32_t *>(ctx->blk_exit.p), static_cast<uint32_t *>(ctx->blk_count.p),
+                                et::ROW_MAP_ONLY | (known ? 0u : et::ROW_START_UNKNOWN), &d_map);
+            ET_HIP(hipGetLastError());
+            ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, d_map, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            ET_HIP(hipMemcpyAsync(ctx->h_scalar + 2, flag + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            ET_HIP(hipStreamSynchronize(ctx->stream));
+            if (*reinterpret_cast<const uint32_t *>(ctx->h_scalar + 2) != 0) return fail(ctx, ET_ERR_HIP, "the row walk's chunks never saw the chunks before them");
+            const uint64_t m = ctx->h_scalar[1];
+            for (uint32_t p = 0; p < 32; ++p) map[p] = static_cast<uint8_t>(p < 8 ? (m >> (8 * p)) & 0xffu : (known ? m & 0xffu : p));
+            *n_starts_out = 8;
+            rs.words = words;
+            rs.n_bytes = n_bytes;
+            rs.n_subs = n_subs;
+            rs.n_blocks = n_blocks;
+            rs.flags = 0;
+            rs.row = true;
+            rs.row_code = row_code;
+            rs.row_cb = *cb;
+            rs.maps_const = known;
+            rs.maps_valid = true;
+            return ET_OK;
+        }
+    }
     const uint32_t n_starts = cb->max_length;
     const uint32_t stride = n_starts <= 8 ? 8 : (n_starts <= 16 ? 16 : 32);
     const size_t n_groups = (static_cast<size_t>(n_blocks) + 255) / 256;
@@ -1442,6 +1488,29 @@ extern "C" int et_decode_range_resolve(et_ctx *ctx, uint32_t in_start_bit, et_ra
     uint32_t *blk_count = static_cast<uint32_t *>(ctx->blk_count.p);
     unsigned long long *blk_off = static_cast<unsigned long long *>(ctx->blk_off.p);
     uint32_t *h_flags = reinterpret_cast<uint32_t *>(ctx->h_scalar + 2);
+    if (rs.row) {  // the same walk again, the start known: every lane's start, exit and count
+        uint32_t *flag = static_cast<uint32_t *>(ctx->flag.p);
+        ET_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), ctx->stream));
+        et::launch_row_sync(ctx->stream, rs.words, rs.n_bytes, in_start_bit, rs.n_subs, rs.row_code, ctx->row_scratch.p, flag + 3, sub_state, blk_exit, blk_count);
+        et::launch_dec_scan(ctx->stream, blk_count, rs.n_blocks, static_cast<unsigned long long *>(ctx->group_sum.p), scan_epoch(ctx), blk_off);
+        ET_HIP(hipGetLastError());
+        ET_HIP(hipMemcpyAsync(ctx->h_scalar + 1, blk_off + rs.n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipMemcpyAsync(h_flags, sub_state, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipMemcpyAsync(h_flags + 1, blk_exit + (rs.n_blocks - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipMemcpyAsync(h_flags + 2, flag + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ET_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_flags[2] != 0) return fail(ctx, ET_ERR_HIP, "the row walk's chunks never saw the chunks before them");
+        rs.total = ctx->h_scalar[1];
+        rs.flags = et::DEC_HAVE_START;
+        rs.first_bit = in_start_bit;
+        rs.valid = true;
+        info->start_bit = h_flags[0] & 0xffu;
+        info->exit_bit = h_flags[1];
+        info->n_symbols = rs.total;
+        info->sweeps = 0;
+        info->reserved = 3;  // row walk
+        return ET_OK;
+    }
     et::launch_dec_resolve(ctx->stream, rs.words, rs.n_bytes, in_start_bit, rs.maps_const, rs.n_subs, rs.tb, rs.map_stride,
                            static_cast<const uint8_t *>(ctx->lane_maps.p), static_cast<const uint8_t *>(ctx->blk_maps.p),
                            static_cast<const uint8_t *>(ctx->grp_maps.p), static_cast<uint8_t *>(ctx->blk_in.p), static_cast<uint8_t *>(ctx->grp_in.p),
@@ -1473,6 +1542,13 @@ extern "C" int et_decode_range_write(et_ctx *ctx, uint64_t max_symbols, void *d_
     if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15)) return fail(ctx, ET_ERR_ARG, "d_out must be 16-byte aligned");
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
     DeviceGuard guard(ctx->device);
+    if (rs.row) {
+        et::launch_row_write(ctx->stream, rs.words, rs.n_bytes, rs.first_bit, rs.n_subs, rs.row_code, &rs.row_cb, static_cast<const uint32_t *>(ctx->sub_state.p),
+                             static_cast<const unsigned long long *>(ctx->blk_off.p), n_out, static_cast<uint8_t *>(d_out));
+        ET_HIP(hipGetLastError());
+        *out_len = static_cast<size_t>(n_out);
+        return ET_OK;
+    }
     et::launch_dec_write(ctx->stream, rs.words, rs.n_bytes, rs.n_subs, rs.tb_write, static_cast<const uint32_t *>(ctx->sub_state.p),
                          static_cast<const unsigned long long *>(ctx->blk_off.p), n_out, static_cast<uint8_t *>(d_out),
                          static_cast<uint32_t *>(ctx->flag.p) + 4, nullptr, false, nullptr, {},

@@ -28,6 +28,9 @@ struct RowCode {
 bool row_code_of(const et_codebook *cb, RowCode *rc);
 
 constexpr uint32_t ROW_CHUNK_BLOCKS = 4;  // 8 KiB blocks a workgroup takes per ticket
+// launch_row_sync flags, for a RANGE of a stream split over GPUs (et_decode_range_maps / _resolve):
+constexpr uint32_t ROW_MAP_ONLY = 1;       // leave the range's map -- byte c = the column the stream behind the range is entered in when the range is entered in column c -- and nothing else
+constexpr uint32_t ROW_START_UNKNOWN = 2;  // the range's first codeword may begin in any column (first_bit is ignored)
 
 }  // namespace et
 
@@ -43,8 +46,9 @@ size_t row_sync_scratch_bytes(uint32_t n_blocks);
 // aligned base, its first codeword at bit first_bit < 32).  Outputs as k_dec_resolve's: sub_state[s] = start bit | exit << 8 |
 // codewords that begin in s << 16; blk_count[b]; blk_exit[b].
 // fault: a device word (zeroed by the caller) that the kernel raises if a chunk never saw what the chunks before it publish (bit 0).
+// flags: 0, or ROW_* above; d_map (optional): receives the device address (inside scratch) of the 8-byte map a ROW_MAP_ONLY launch leaves.
 void launch_row_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, RowCode rc, void *scratch, uint32_t *fault,
-                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count);
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t flags = 0, const unsigned long long **d_map = nullptr);
 
 // The write pass for such a stream, by rows (k_row_write): sub_state as launch_row_sync leaves it, blk_off from the scan of
 // blk_count; at most n_symbols symbols to out (16-byte aligned).  ev_start / ev_stop: events the dispatch carries (may be null).

@@ -94,7 +94,11 @@ struct RsShared {
 __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, uint32_t n_blocks,
                                                          uint32_t n_chunks, uint32_t code_t, unsigned long long *__restrict__ pub, uint32_t *__restrict__ ticket,
                                                          uint32_t *__restrict__ fault, uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
-                                                         uint32_t *__restrict__ blk_count) {
+                                                         uint32_t *__restrict__ blk_count, uint32_t flags, unsigned long long *__restrict__ map_out) {
+    // flags (a RANGE of a stream split over GPUs): ROW_MAP_ONLY -- leave the range's MAP (entry column -> exit column) in *map_out and
+    // nothing else: every chunk publishes its map, the last one composes them all; ROW_START_UNKNOWN -- the first subsequence is a
+    // subsequence like any other (its first codeword may begin in any column).
+    const bool map_only = (flags & ROW_MAP_ONLY) != 0, start_known = !(flags & ROW_START_UNKNOWN);
     __shared__ RsShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t n_bits = n_bytes * 8, n_words_full = n_bytes / 4;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
             const bool live = sub_g < n_subs;
             const uint64_t sub_end = (sub_g + 1) * 256;
             uint32_t e_lo = ID_LO, e_hi = ID_HI, c_lo = 0, c_hi = 0;  // (a subsequence past the stream's end: nothing happens in it)
-            const bool slow = live && (sub_g == 0 || sub_end + 8 > n_bits);
+            const bool slow = live && ((sub_g == 0 && start_known) || sub_end + 8 > n_bits);
             if (live && !slow) {
                 uint32_t w[9];
                 const bool interior = static_cast<uint64_t>(b + 1) * 2048 + 1 <= n_words_full;  // wavefront-uniform
@@ -209,11 +213,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
                 e_lo = e_hi = c_lo = c_hi = 0;
                 for (uint32_t c0 = 0; c0 < 8; ++c0) {
                     uint32_t ex = 0, cnt = 0;
-                    if (sub_g == 0 && c0 > 0) {  // (a constant map)
+                    if (sub_g == 0 && start_known && c0 > 0) {  // (a constant map)
                         ex = e_lo & 0xffu;
                         cnt = c_lo & 0xffu;
                     } else {
-                        const uint32_t r = rs_slow_walk(bytes, n_bytes, sub_g == 0 ? first_bit : sub_g * 256 + c0, sub_end, code_t);
+                        const uint32_t r = rs_slow_walk(bytes, n_bytes, (sub_g == 0 && start_known) ? first_bit : sub_g * 256 + c0, sub_end, code_t);
                         ex = r & 0xffu;
                         cnt = r >> 8;
                     }
@@ -246,13 +250,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
                 f_lo = n_lo, f_hi = n_hi;
             }
             uint32_t entry = 0;  // (the stream's first chunk: its first lane's map is constant)
-            if (c > 0) {
+            const bool look_back = map_only ? c + 1 == n_chunks : c > 0;  // (a range's map: only the last chunk looks, and all the way)
+            if (c > 0 || map_only) {
                 const unsigned long long mine = (static_cast<unsigned long long>(f_lo) | (static_cast<unsigned long long>(f_hi) << 32)) | KIND_MAP;
                 if (lane == 0) __hip_atomic_store(pub + c, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // g: from the entry column of chunk i + 1 to ours; 64 chunks per look, nearest first
-                uint32_t g_lo = ID_LO, g_hi = ID_HI;
+            }
+            // g: from the entry column of chunk i + 1 to ours; 64 chunks per look, nearest first
+            uint32_t g_lo = ID_LO, g_hi = ID_HI;
+            if (look_back) {
                 long long i = static_cast<long long>(c) - 1;
-                for (uint32_t spins = 0;;) {
+                for (uint32_t spins = 0; i >= 0;) {
                     const long long idx = i - static_cast<long long>(lane);
                     unsigned long long v = 0;
                     if (idx >= 0) v = __hip_atomic_load(pub + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -276,16 +283,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
                         g_lo = n_lo, g_hi = n_hi;
                     }
                     if (first_known < use) break;  // (g is constant now: the entry column)
-                    i -= use;
+                    i -= use;  // (a range's map: on until the range's first chunk is in)
                 }
                 entry = g_lo & 7u;
             }
-            const uint32_t out_col = map_at(f_lo, f_hi, entry);
-            if (lane == 0) {
-                __hip_atomic_store(pub + c, static_cast<unsigned long long>(out_col) * 0x0101010101010101ull | KIND_ENTRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh.entry = entry;
+            if (map_only) {
+                if (look_back && lane == 0) {  // the whole range: first g (everything before this chunk), then this chunk's own
+                    const uint32_t t_lo = perm(f_hi, f_lo, g_lo), t_hi = perm(f_hi, f_lo, g_hi);
+                    *map_out = static_cast<unsigned long long>(t_lo) | (static_cast<unsigned long long>(t_hi) << 32);
+                }
+            } else {
+                const uint32_t out_col = map_at(f_lo, f_hi, entry);
+                if (lane == 0) {
+                    __hip_atomic_store(pub + c, static_cast<unsigned long long>(out_col) * 0x0101010101010101ull | KIND_ENTRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh.entry = entry;
+                }
             }
         }
+        if (map_only) continue;  // (nothing per lane to leave; the loop's first barrier keeps the LDS in step)
         __syncthreads();
 
         // ---- every lane's start, exit and count ----------------------------------------------------------------------------------
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restr
             const uint32_t before = __shfl_up(out_col, 1);
             const uint32_t in_col = lane ? before : wave_in;
             const uint32_t cnt = live ? map_at(static_cast<uint32_t>(lc), static_cast<uint32_t>(lc >> 32), in_col) : 0u;
-            if (live) sub_state[sub_g] = (sub_g == 0 ? first_bit : in_col) | (out_col << 8) | (cnt << 16);
+            if (live) sub_state[sub_g] = ((sub_g == 0 && start_known) ? first_bit : in_col) | (out_col << 8) | (cnt << 16);
             uint32_t sum = cnt;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
@@ -481,17 +496,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_row_write(const uint32_t *__rest
 
 size_t row_sync_scratch_bytes(uint32_t n_blocks) {
     const size_t n_chunks = (static_cast<size_t>(n_blocks) + RS_CH - 1) / RS_CH;
-    return n_chunks * sizeof(unsigned long long) + 64;
+    return n_chunks * sizeof(unsigned long long) + 64;  // the chunks' words, then: ticket (4 bytes), pad, the range's map (8 bytes at + 8)
 }
 
 void launch_row_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, RowCode rc, void *scratch, uint32_t *fault,
-                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count) {
+                     uint32_t *sub_state, uint32_t *blk_exit, uint32_t *blk_count, uint32_t flags, const unsigned long long **d_map) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + RS_THREADS - 1) / RS_THREADS);
     const uint32_t n_chunks = (n_blocks + RS_CH - 1) / RS_CH;
     if (!n_chunks) return;
     (void)hipMemsetAsync(scratch, 0, row_sync_scratch_bytes(n_blocks), stream);  // "nothing published", ticket 0
     unsigned long long *pub = static_cast<unsigned long long *>(scratch);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(pub + n_chunks);
+    unsigned long long *map_out = pub + n_chunks + 1;
+    if (d_map) *d_map = map_out;
     static thread_local int seen_dev = -1, cus = 256;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -502,7 +519,7 @@ void launch_row_sync(hipStream_t stream, const uint32_t *words, uint64_t n_bytes
     uint32_t grid = static_cast<uint32_t>(cus) * 8u;  // (workgroups that find no room wait their turn and take later tickets: nobody waits for them)
     if (grid > n_chunks) grid = n_chunks;
     hipLaunchKernelGGL(k_row_sync, dim3(grid), dim3(RS_THREADS), 0, stream, words, n_bytes, first_bit, n_subs, n_blocks, n_chunks, rc.t, pub, ticket, fault, sub_state, blk_exit,
-                       blk_count);
+                       blk_count, flags, map_out);
 }
 
 void launch_row_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, RowCode rc, const et_codebook *cb,

@@ -266,6 +266,9 @@ def test_cold_decode_exhaustive_virtual_ranks(ranks):
     from oracle import oracle as O
 
     for data in (corpus.uniform(900_001, 31, 1, 256), corpus.uniform(500_000, 32, 10, 10 + 100)):
+        # (255 symbols: a complete code of 7 and 8 bits -- the ranges' maps and starts by rows and columns, csrc/et_rowsync.hip;
+        # 100 symbols: 6 and 7 bits -- the exit maps for every start offset, csrc/et_kernels_fallback.hip)
+        by_rows = data.max() > 200
         et = O.encode(data)
         comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy()).cuda()
         cb, n_symbols, body_off = E.parse_header(et[4:])
@@ -288,7 +291,7 @@ def test_cold_decode_exhaustive_virtual_ranks(ranks):
             out, first, s_in = [], 0, first_bit
             for c, m in zip(ctxs, maps):
                 inf = c.decode_range_resolve(s_in)
-                assert inf["start_bit"] == s_in and inf["exit_bit"] == m[s_in]
+                assert inf["start_bit"] == s_in and inf["exit_bit"] == m[s_in] and inf["row_walk"] == by_rows
                 s_in = m[s_in]
                 take = max(0, min(inf["n_symbols"], n_symbols - first))
                 buf = torch.empty(inf["n_symbols"] + 64, dtype=torch.uint8, device="cuda")

@@ -189,6 +189,54 @@ def test_large_stream_many_chunks_in_flight(ctx):
         assert m == n and torch.equal(dec[:n], text)
 
 
+@pytest.mark.parametrize("k,ranks", [(255, 2), (255, 7), (200, 3), (130, 5)])
+def test_ranges_of_a_stream_split_over_ranks(k, ranks):
+    """et_decode_range_maps / _resolve / _write on a row code's stream cut into block ranges, each on its own et_ctx (what
+    et_decode_sharded does on N GPUs): a range's MAP -- entry column -> the column the next range is entered in -- comes from one
+    pass in which every chunk publishes its map and the last one composes them; the maps are chained by hand here as the group's
+    exchange chains them, every range is resolved from its true start and written by rows; the pieces are the oracle's decode."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    data = flat(k, 700_001 + 1000 * ranks, 500 + k)
+    et = O.encode(data.tobytes())
+    comp = torch.from_numpy(np.frombuffer(et[4:], dtype=np.uint8).copy()).cuda()
+    cb, n_symbols, body_off = E.parse_header(et[4:])
+    ptr = comp.data_ptr() + body_off
+    base_off, first_bit = body_off - (ptr & 3), (ptr & 3) * 8
+    stream = comp[base_off:]
+    n_blocks = (stream.numel() + 8191) // 8192
+    ctxs, maps = [], []
+    try:
+        for r in range(ranks):
+            lo, hi = r * n_blocks // ranks, (r + 1) * n_blocks // ranks
+            c = E.Context(0)
+            begin, end = lo * 8192, min(hi * 8192, stream.numel())
+            m, n_starts = c.decode_range_maps(cb, stream, begin, end, first_bit if lo == 0 else -1)
+            assert n_starts == 8
+            if lo == 0:
+                assert len(set(m[:8])) == 1, "the stream's first range begins at a known bit: a constant map"
+            ctxs.append(c)
+            maps.append(m)
+        out, first, s_in = [], 0, first_bit
+        for c, m in zip(ctxs, maps):
+            inf = c.decode_range_resolve(s_in)
+            assert inf["row_walk"] and inf["start_bit"] == s_in and inf["exit_bit"] == m[s_in], (inf, m[:8], s_in)
+            s_in = m[s_in]
+            take = max(0, min(inf["n_symbols"], n_symbols - first))
+            buf = torch.empty(inf["n_symbols"] + 64, dtype=torch.uint8, device="cuda")
+            got = c.decode_range_write(take, buf)
+            torch.cuda.synchronize()
+            out.append(buf[:got].cpu().numpy())
+            first += inf["n_symbols"]
+        assert np.concatenate(out).tobytes() == data.tobytes()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.parametrize("switch", ["ET_NO_ROW_SYNC", "ET_NO_ROW_WRITE"])
 def test_fallback_exit_maps_still_decode_these_streams(switch):
     """ET_NO_ROW_SYNC=1 (a child process: the switch is read once): the same streams through k_dec_maps_reg / k_dec_resolve_reg
