@@ -136,6 +136,32 @@ def test_body_alignments_and_start_bits(ctx):
             assert m == data.size and out[:m].cpu().numpy().tobytes() == data.tobytes(), (start_bit, shift)
 
 
+def test_declared_length_shorter_than_the_body(ctx):
+    """The declared symbol count is what a decode returns at most: a count that ends inside a wavefront's 64 subsequences, on a
+    16-byte boundary of the output, one symbol, and more than the body holds (the pad bits then decode as whatever they say)."""
+    import torch
+
+    import entreepy_amd as E
+
+    O = _oracle()
+    h = np.zeros(256, dtype=np.uint64)
+    h[1:] = 100
+    cb = E.Codebook.from_histogram(h)
+    data = flat(255, 200_000, 21, lo=1)
+    body, end_bit = O.pack_body(cb.data, cb.length, data, 0)
+    buf = torch.frombuffer(bytearray(body) + bytearray(64), dtype=torch.uint8).cuda()
+    out = torch.full((data.size + 256,), 0xEE, dtype=torch.uint8, device="cuda")
+    for n_decl in (1, 15, 16, 17, 2047, 2048, 8191, 8192 * 3 + 5, 100_000, data.size - 1, data.size):
+        out.fill_(0xEE)
+        m = ctx.decode_body_device(cb, buf[: (end_bit + 7) // 8], n_decl, out, 0)
+        got = out.cpu().numpy()
+        assert m == n_decl and got[:m].tobytes() == data[:m].tobytes(), n_decl
+        assert (got[m + 16 :] == 0xEE).all(), f"bytes written far behind the {n_decl} declared symbols"
+    # more declared than there are codewords: every codeword of the body, pad bits included, and no more
+    m = ctx.decode_body_device(cb, buf[: (end_bit + 7) // 8], data.size + 100, out, 0)
+    assert data.size <= m <= data.size + 1 and out[: data.size].cpu().numpy().tobytes() == data.tobytes()
+
+
 def test_fuzzed_bodies_match_the_oracle(ctx):
     """Bit flips, junk and all-ones / all-zeros runs in the body: any bit pattern is a codeword of a complete code, so the
     decode is whatever the bits say -- and equals the oracle's."""
