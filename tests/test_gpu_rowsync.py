@@ -162,6 +162,46 @@ def test_declared_length_shorter_than_the_body(ctx):
     assert data.size <= m <= data.size + 1 and out[: data.size].cpu().numpy().tobytes() == data.tobytes()
 
 
+@pytest.mark.parametrize("t", [0, 1, 5, 64, 127])
+def test_hand_made_row_dictionaries(ctx, t):
+    """Row codes that no encoder made: the 7-bit codewords 0 .. t-1 and the 8-bit codewords 2t .. 255 handed to symbols in random
+    order (t = 0: all 256 byte values with 8 bits each, which the reference's own encoder cannot produce -- it drops one of 256, Q1).
+    The body is packed by the oracle with that table; the decode must return the text (the symbol table of the write pass is filled
+    from the dictionary, not from an order the encoder would have used)."""
+    import ctypes
+
+    import torch
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+
+    O = _oracle()
+    rng = np.random.default_rng(900 + t)
+    n_sym = 256 - t
+    syms = rng.permutation(256)[:n_sym]
+    data_t = np.zeros(256, dtype=np.uint32)
+    len_t = np.zeros(256, dtype=np.uint8)
+    codes = [(v, 7) for v in range(t)] + [(v, 8) for v in range(2 * t, 256)]
+    assert len(codes) == n_sym
+    for s, (v, ln) in zip(syms, [codes[i] for i in rng.permutation(n_sym)]):
+        data_t[s], len_t[s] = v, ln
+    cb = E.Codebook.from_tables(data_t, len_t)
+    got_t = ctypes.c_uint32(999)
+    assert N.lib().et_row_code(ctypes.byref(cb.raw), ctypes.byref(got_t)) == N.ET_OK and got_t.value == t
+    text = syms[rng.integers(0, n_sym, size=150_001)].astype(np.uint8)
+    for start_bit in (0, 3):
+        body, end_bit = O.pack_body(cb.data, cb.length, text, start_bit)
+        buf = torch.frombuffer(bytearray(body) + bytearray(64), dtype=torch.uint8).cuda()
+        out = torch.empty(text.size + 64, dtype=torch.uint8, device="cuda")
+        ctx.enable_timing(True)
+        try:
+            m = ctx.decode_body_device(cb, buf[: (end_bit + 7) // 8], text.size, out, start_bit)
+            tm = ctx.timings("decode")
+        finally:
+            ctx.enable_timing(False)
+        assert tm["row_sync"] and m == text.size and out[:m].cpu().numpy().tobytes() == text.tobytes(), (t, start_bit)
+
+
 def test_fuzzed_bodies_match_the_oracle(ctx):
     """Bit flips, junk and all-ones / all-zeros runs in the body: any bit pattern is a codeword of a complete code, so the
     decode is whatever the bits say -- and equals the oracle's."""
