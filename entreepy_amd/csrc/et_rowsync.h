@@ -27,7 +27,10 @@ struct RowCode {
 // values 0 .. n7-1.  (No HIP in this function: et_rowsync_host.cpp compiles with plain g++.)
 bool row_code_of(const et_codebook *cb, RowCode *rc);
 
-constexpr uint32_t ROW_CHUNK_BLOCKS = 4;  // 8 KiB blocks a workgroup takes per ticket
+#ifndef ET_ROW_CHUNK_BLOCKS
+#define ET_ROW_CHUNK_BLOCKS 4
+#endif
+constexpr uint32_t ROW_CHUNK_BLOCKS = ET_ROW_CHUNK_BLOCKS;  // 8 KiB blocks a workgroup takes per ticket (measured: 2 / 4 / 8)
 // launch_row_sync flags, for a RANGE of a stream split over GPUs (et_decode_range_maps / _resolve):
 constexpr uint32_t ROW_MAP_ONLY = 1;       // leave the range's map -- byte c = the column the stream behind the range is entered in when the range is entered in column c -- and nothing else
 constexpr uint32_t ROW_START_UNKNOWN = 2;  // the range's first codeword may begin in any column (first_bit is ignored)

@@ -91,7 +91,10 @@ struct RsShared {
 
 }  // namespace
 
-__global__ __launch_bounds__(RS_THREADS) void k_row_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, uint32_t n_blocks,
+#ifndef ET_ROW_SYNC_ATTR
+#define ET_ROW_SYNC_ATTR
+#endif
+__global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, uint32_t n_blocks,
                                                          uint32_t n_chunks, uint32_t code_t, unsigned long long *__restrict__ pub, uint32_t *__restrict__ ticket,
                                                          uint32_t *__restrict__ fault, uint32_t *__restrict__ sub_state, uint32_t *__restrict__ blk_exit,
                                                          uint32_t *__restrict__ blk_count, uint32_t flags, unsigned long long *__restrict__ map_out) {
