@@ -2,11 +2,13 @@
 // context, workspaces, and the orchestration of the kernels in et_kernels.hip, et_treewalk.hip, et_rowsync.hip and et_kernels_fallback.hip.
 //
 // Encode (replaces encode.zig:25-337):
-//   K1 histogram -> D2H 2 KiB -> host code construction (et_codebook.cpp) -> H2D code
-//   table + header -> K2 tile bit totals + scan -> K4 code scatter.
+//   K1 histogram (totals stored into pinned host memory, polled) -> host code construction (et_codebook.cpp) -> K2 tile bit totals
+//   (its first workgroup takes the code table and the header out of the pinned block) + scan -> K4 code scatter.
 // Decode (replaces decode.zig:13-220):
-//   D2H header -> host parse + lookup tables -> D1 synchronisation sweeps (until a
-//   sweep reports no change) -> D2 scan of workgroup symbol counts -> D3 write.
+//   header to pinned host memory (polled) -> host parse, the code as a tree + the chained tables' plan -> k_tw_build -> D1
+//   synchronisation by tree walk (one launch; repair sweeps only if the verification fails) -> D2 scan of the blocks' symbol counts
+//   (+ verification, report to the host) -> D3 write over chained tables.  Complete codes of 7- and 8-bit codewords (uniform-like
+//   bytes): k_row_sync -> D2 -> k_row_write (et_rowsync.h).  Anything outside those two walks' domains: et_kernels_fallback.hip.
 // There is no CPU fallback anywhere in this file: without a usable HIP device every
 // entry point returns ET_ERR_HIP.
 #include "entreepy_hip.h"

@@ -64,7 +64,7 @@ typedef struct et_timings {
     float sync_ms;      /* decode: everything in front of the write kernel (sweeps, verification, scan) */
     float total_ms;     /* begin of the first large kernel to the end of the last */
     uint32_t sync_iters;/* decode: synchronisation launches */
-    uint32_t reserved;  /* decode: bit 0 = the exhaustive synchronisation path ran, bit 1 = the sweeps ran as a tree walk, bit 2 = the write pass used the chained tables */
+    uint32_t reserved;  /* decode: bit 0 = the exhaustive synchronisation path ran, bit 1 = the sweeps ran as a tree walk, bit 2 = the write pass used the chained tables, bit 3 = synchronised (and, unless switched off, written) by rows: a complete code of 7- and 8-bit codewords, et_row_code */
     float sync_first_ms;/* decode: the first synchronisation sweep alone (k_dec_sync<first>) */
     uint32_t pad_;
 } et_timings;
