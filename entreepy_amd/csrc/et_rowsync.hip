@@ -181,28 +181,30 @@ __global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const 
                 bool lane_stuck = false;
 #pragma unroll
                 for (int c0 = 0; c0 < 8; ++c0) {
-                    uint32_t rows = 0xffffffffu, wraps = 0, ex = static_cast<uint32_t>(c0);
-                    bool act = true;
-                    for (uint32_t lap = 0; lap < 6 && __any(act); ++lap) {  // (<= 32 + 5 steps: all but the last are 7-bit codes, each in a row of its own but for <= 5)
+                    // `rows` = the rows still ahead of the path in the column it looks at next (0: the path has left the subsequence);
+                    // `hits` = the 7-bit codes it has met: it leaves in column (c0 - hits) & 7.  Per iteration: and, compare, v_ffbl, shift,
+                    // select, add-with-carry -- and the compare's lane mask IS "somebody is still walking": no instruction for the test.
+                    uint32_t rows = 0xffffffffu, hits = 0, wraps = 0;
+                    bool more = true;
+                    for (uint32_t lap = 0; lap < 6 && more; ++lap) {  // (<= 32 + 5 steps: all but the last are 7-bit codes, each in a row of its own but for <= 5)
 #pragma unroll
                         for (int it = 0; it < 8; ++it) {
                             const int col = (c0 - it) & 7;
                             const uint32_t m = S[col] & rows;
-                            const bool some = m != 0, hit = act && some;
-                            ex = (act && !some) ? static_cast<uint32_t>(col) : ex;  // nothing more in this column: the path leaves the subsequence in it
-                            act = hit;
+                            const bool some = m != 0;
                             uint32_t j;
                             asm("v_ffbl_b32 %0, %1" : "=v"(j) : "v"(m));
                             // a 7-bit code at (j, col) ends at (j + 1, col - 1): the rows below j -- from column 0 it ends at (j, 7): row j too.
-                            // (from row 31 nothing is left below: the next iteration finds nothing and records column col - 1)
-                            const uint32_t below = (col == 0 ? 0xffffffffu : 0xfffffffeu) << j;
-                            rows = hit ? below : rows;
-                            if (col == 0) wraps += hit ? 1u : 0u;  // two codewords begin in row j
-                            if (it < 7 && !__any(act)) break;
+                            // (from row 31 nothing is left below: the next iteration finds nothing, and the hit before it has moved the column)
+                            rows = some ? (col == 0 ? 0xffffffffu : 0xfffffffeu) << j : 0u;
+                            hits += some ? 1u : 0u;
+                            if (col == 0) wraps += some ? 1u : 0u;  // two codewords begin in row j
+                            more = __builtin_amdgcn_ballot_w64(some) != 0;
+                            if (!more) break;
                         }
                     }
-                    lane_stuck = lane_stuck || act;
-                    const uint32_t cnt = 32u + wraps;
+                    lane_stuck = lane_stuck || more;
+                    const uint32_t ex = (static_cast<uint32_t>(c0) - hits) & 7u, cnt = 32u + wraps;
                     if (c0 == 0) e_lo = ex, c_lo = cnt;
                     else if (c0 < 4) e_lo |= ex << (8 * c0), c_lo |= cnt << (8 * c0);
                     else if (c0 == 4) e_hi = ex, c_hi = cnt;
