@@ -37,6 +37,8 @@ constexpr uint32_t RS_SPINS = 1u << 24;         // looks at a word that never co
 constexpr unsigned long long KIND_MAP = 1ull << 3, KIND_ENTRY = 2ull << 3;  // in byte 0 of a published word, above the column's 3 bits
 
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// a & ~b (left to the compiler: it inverts each plane once and ands -- an explicit v_bfi_b32 per use measured 3 % SLOWER, 2.52 against 2.46 ms)
+__device__ __forceinline__ uint32_t rs_and_not(uint32_t a, uint32_t b) { return a & ~b; }
 // byte `idx` (0..7) of the 8-byte map {lo, hi}
 __device__ __forceinline__ uint32_t map_at(uint32_t lo, uint32_t hi, uint32_t idx) { return perm(hi, lo, idx | 0x0c0c0c00u); }
 
@@ -80,6 +82,18 @@ __device__ __attribute__((noinline)) uint32_t rs_slow_walk(const uint8_t *__rest
     return exit_col | (n << 8);
 }
 
+__device__ __forceinline__ uint32_t rs_wave_sum_scan(uint32_t x) {  // inclusive prefix sum over the wavefront (DPP)
+#define RS_DPP_ADD(ctrl_, mask_) x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), ctrl_, mask_, 0xf, false))
+    RS_DPP_ADD(0x111, 0xf);
+    RS_DPP_ADD(0x112, 0xf);
+    RS_DPP_ADD(0x114, 0xf);
+    RS_DPP_ADD(0x118, 0xf);
+    RS_DPP_ADD(0x142, 0xa);
+    RS_DPP_ADD(0x143, 0xc);
+#undef RS_DPP_ADD
+    return x;
+}
+
 struct RsShared {
     unsigned long long lane_pre[RS_CH][RS_THREADS];  // a lane's INCLUSIVE prefix map inside its wavefront
     unsigned long long lane_cnt[RS_CH][RS_THREADS];  // codewords that begin in the lane's subsequence, per entry column (a byte each)
@@ -105,6 +119,9 @@ __global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const 
     __shared__ RsShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t n_bits = n_bytes * 8, n_words_full = n_bytes / 4;
+    // the first subsequence whose last row's codeword may be cut by the stream's end ((s + 1) * 256 + 8 > n_bits): the lanes from there on
+    // walk one codeword at a time (a scalar, worked out once: the lanes' own test is one compare)
+    const uint64_t first_tail_sub = n_bits >= 264 ? (n_bits - 8) / 256 : 0;
     for (;;) {
         __syncthreads();  // everybody is done with the chunk before
         if (tid == 0) sh.chunk = atomicAdd(ticket, 1u);
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const 
             const bool live = sub_g < n_subs;
             const uint64_t sub_end = (sub_g + 1) * 256;
             uint32_t e_lo = ID_LO, e_hi = ID_HI, c_lo = 0, c_hi = 0;  // (a subsequence past the stream's end: nothing happens in it)
-            const bool slow = live && ((sub_g == 0 && start_known) || sub_end + 8 > n_bits);
+            const bool slow = live && ((sub_g == 0 && start_known) || sub_g >= first_tail_sub);
             if (live && !slow) {
                 uint32_t w[9];
                 const bool interior = static_cast<uint64_t>(b + 1) * 2048 + 1 <= n_words_full;  // wavefront-uniform
@@ -167,12 +184,12 @@ __global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const 
                     if ((code_t >> (6 - i)) & 1u) {  // t has a 1 here: rows with a 0 (and equal so far) are below t; the others stay equal
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
-                            S[r] |= eq[r] & ~B[r + i];
+                            S[r] |= rs_and_not(eq[r], B[r + i]);
                             eq[r] &= B[r + i];
                         }
                     } else {  // t has a 0 here: rows with a 1 are above it
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) eq[r] &= ~B[r + i];
+                        for (int r = 0; r < 8; ++r) eq[r] = rs_and_not(eq[r], B[r + i]);
                     }
                 }
                 // 4. the path from every entry column: in column (c0 - it) & 7 at iteration `it`, down to the next 7-bit code in that
@@ -230,14 +247,24 @@ __global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const 
                     else e_hi |= ex << (8 * (c0 - 4)), c_hi |= cnt << (8 * (c0 - 4));
                 }
             }
-            // 5. inclusive scan of the wavefront's maps: pre_i = f_i o ... o f_0 (first f_0), by v_perm
+            // 5. inclusive scan of the wavefront's maps: pre_i = f_i o ... o f_0 (first f_0).  The scan's moves are DPP (row_shr 1, 2, 4, 8
+            //    inside the rows of 16 lanes, then row_bcast:15 / :31 across them -- as a prefix sum's); a lane nothing moves into keeps the
+            //    identity map, and composing with the identity is no change: no lane test.  4 VALU instructions per step, 24 in all.
             uint32_t p_lo = e_lo, p_hi = e_hi;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o_lo = __shfl_up(p_lo, d), o_hi = __shfl_up(p_hi, d);  // the map of the lanes before
-                const uint32_t n_lo = perm(p_hi, p_lo, o_lo), n_hi = perm(p_hi, p_lo, o_hi);  // first theirs, then ours
-                if (lane >= static_cast<uint32_t>(d)) p_lo = n_lo, p_hi = n_hi;
-            }
+#define RS_SCAN_STEP(ctrl_, row_mask_)                                                                                                             \
+    {                                                                                                                                              \
+        const uint32_t o_lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(ID_LO), static_cast<int>(p_lo), ctrl_, row_mask_, 0xf, false)); \
+        const uint32_t o_hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(ID_HI), static_cast<int>(p_hi), ctrl_, row_mask_, 0xf, false)); \
+        const uint32_t n_lo = perm(p_hi, p_lo, o_lo), n_hi = perm(p_hi, p_lo, o_hi); /* first theirs, then ours */                                 \
+        p_lo = n_lo, p_hi = n_hi;                                                                                                                  \
+    }
+            RS_SCAN_STEP(0x111, 0xf)  // row_shr:1
+            RS_SCAN_STEP(0x112, 0xf)  // row_shr:2
+            RS_SCAN_STEP(0x114, 0xf)  // row_shr:4
+            RS_SCAN_STEP(0x118, 0xf)  // row_shr:8   -> every row of 16 scanned
+            RS_SCAN_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+            RS_SCAN_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef RS_SCAN_STEP
             sh.lane_pre[q][tid] = static_cast<unsigned long long>(p_lo) | (static_cast<unsigned long long>(p_hi) << 32);
             sh.lane_cnt[q][tid] = static_cast<unsigned long long>(c_lo) | (static_cast<unsigned long long>(c_hi) << 32);
             if (lane == 63) sh.wave_map[q * 4 + wv] = static_cast<unsigned long long>(p_lo) | (static_cast<unsigned long long>(p_hi) << 32);
@@ -317,14 +344,12 @@ __global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const 
             const unsigned long long wp = sh.wave_pre[q * 4 + wv], lp = sh.lane_pre[q][tid], lc = sh.lane_cnt[q][tid];
             const uint32_t wave_in = map_at(static_cast<uint32_t>(wp), static_cast<uint32_t>(wp >> 32), entry);
             const uint32_t out_col = map_at(static_cast<uint32_t>(lp), static_cast<uint32_t>(lp >> 32), wave_in);  // behind this lane
-            const uint32_t before = __shfl_up(out_col, 1);
-            const uint32_t in_col = lane ? before : wave_in;
+            // the column this lane is entered in = the one behind the lane before it (DPP wave_shr:1; lane 0 keeps the wavefront's)
+            const uint32_t in_col = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(wave_in), static_cast<int>(out_col), 0x138, 0xf, 0xf, false));
             const uint32_t cnt = live ? map_at(static_cast<uint32_t>(lc), static_cast<uint32_t>(lc >> 32), in_col) : 0u;
             if (live) sub_state[sub_g] = ((sub_g == 0 && start_known) ? first_bit : in_col) | (out_col << 8) | (cnt << 16);
-            uint32_t sum = cnt;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-            if (lane == 0) sh.wave_count[q * 4 + wv] = sum;
+            const uint32_t sum = rs_wave_sum_scan(cnt);  // (inclusive prefix by DPP: lane 63 holds the wavefront's total)
+            if (lane == 63) sh.wave_count[q * 4 + wv] = sum;
             if (tid == RS_THREADS - 1) blk_exit[b] = out_col;
         }
         __syncthreads();
