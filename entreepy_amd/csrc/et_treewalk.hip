@@ -364,9 +364,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ET_TW_WAVE
             // lane li's start must be lane li - 1's exit (li = u * 64 + lane); the block's first lane keeps its own
             bool need[TW_LANES], any_need = false;
             uint32_t cand[TW_LANES];
-            const uint32_t up0 = __shfl_up(r[0].s_out(), 1), up1 = __shfl_up(r[1].s_out(), 1), last0 = __shfl(r[0].s_out(), 63);
-            cand[0] = lane_id ? up0 : start[0];
-            cand[1] = lane_id ? up1 : last0;
+            // the lane before's exit by DPP (wave_shr:1; lane 0 keeps what is handed in as `old`: its own start / the exit of lane 63
+            // of the other half, a scalar) -- the shuffles were ds_bpermute round trips on the seam loop's dependent path
+            const uint32_t out0 = r[0].s_out(), out1 = r[1].s_out();
+            const uint32_t last0 = __builtin_amdgcn_readlane(out0, 63);
+            cand[0] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(start[0]), static_cast<int>(out0), 0x138, 0xf, 0xf, false));
+            cand[1] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(last0), static_cast<int>(out1), 0x138, 0xf, 0xf, false));
 #pragma unroll
             for (int u = 0; u < TW_LANES; ++u) {
                 need[u] = live[u] && cand[u] != start[u];
@@ -474,7 +477,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ET_TW_WAVE
         uint32_t b_again = b;
         asm volatile("" : "+v"(b_again));
         uint32_t sum = 0;
-        const uint32_t next_st0 = __shfl_down(st1[0], 1), next_st1 = __shfl_down(st1[1], 1), first1 = __shfl(st1[1], 0);
+        // (wave_shl:1: the lane behind's; lane 63 keeps `old`, which the selects below never look at)
+        const uint32_t next_st0 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(st1[0]), 0x130, 0xf, 0xf, false));
+        const uint32_t next_st1 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(st1[1]), 0x130, 0xf, 0xf, false));
+        const uint32_t first1 = __builtin_amdgcn_readlane(st1[1], 0);
 #pragma unroll
         for (int u = 0; u < TW_LANES; ++u) {
             const uint32_t begun1 = r[u].c1() - ((start[u] != 0 && f1[u]) ? 1u : 0u) + ((r[u].s_mid() != 0 && f2[u]) ? 1u : 0u);
