@@ -30,7 +30,13 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     n_ctx = int(os.environ.get("ET_PROBE_CONTEXTS", 2))
-    texts = [corpus.text_like_torch(n, 0x5EED0004 + i, dev) for i in range(n_ctx)]
+    if os.environ.get("ET_PROBE_DATA") == "uniform255":  # (the row walk's kernels: k_row_sync the VALU, k_row_write the memory)
+        import bench
+
+        texts = [bench.uniform_bytes_torch(n, 1, 256, 0x5EED0255 + i, dev) for i in range(n_ctx)]
+    else:
+        texts = [corpus.text_like_torch(n, 0x5EED0004 + i, dev) for i in range(n_ctx)]
+    decode_only = os.environ.get("ET_PROBE_DECODE_ONLY") == "1"
     lanes = []
     for i in range(n_ctx):
         ctx = E.Context(0)
@@ -44,8 +50,10 @@ def main():
 
     def run(lane, k):
         ctx, pipe, text, enc, dec = lane
+        r = pipe.encode_shard(text, enc, timings=False)
         for _ in range(k):
-            r = pipe.encode_shard(text, enc, timings=False)
+            if not decode_only:
+                r = pipe.encode_shard(text, enc, timings=False)
             pipe.decode_shard(enc, r, dec)
 
     def timed(active, k):
@@ -63,7 +71,7 @@ def main():
         return time.perf_counter() - t0
 
     for lane in lanes:  # warm-up + check
-        run(lane, 100)
+        run(lane, 20)
         torch.cuda.synchronize()
         assert torch.equal(lane[4][:n], lane[2]), "round trip differs"
     out = {"bytes": n, "steps": steps}
