@@ -23,7 +23,7 @@ struct RowCode {
     uint32_t t;  // the 7-bit values 0 .. t-1 are codewords; every other codeword has 8 bits
 };
 
-// true when cb is such a code: lengths 7 and 8 only, complete (2 * n7 + n8 = 256), prefix-free, the 7-bit codes are the
+// true when cb is such a code: lengths 7 and 8 only (or 7 only: 128 codewords, t = 128), complete (2 * n7 + n8 = 256), prefix-free, the 7-bit codes are the
 // values 0 .. n7-1.  (No HIP in this function: et_rowsync_host.cpp compiles with plain g++.)
 bool row_code_of(const et_codebook *cb, RowCode *rc);
 

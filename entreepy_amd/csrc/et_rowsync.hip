@@ -192,6 +192,10 @@ __global__ __launch_bounds__(RS_THREADS) ET_ROW_SYNC_ATTR void k_row_sync(const 
                         for (int r = 0; r < 8; ++r) eq[r] = rs_and_not(eq[r], B[r + i]);
                     }
                 }
+                if (code_t >= 128u) {  // (128 codewords of 7 bits and no other: t does not fit the comparator's 7 bits)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) S[r] = 0xffffffffu;
+                }
                 // 4. the path from every entry column: in column (c0 - it) & 7 at iteration `it`, down to the next 7-bit code in that
                 //    column (then one column to the left, from the row below) or to the subsequence's end.  `rows` = the rows still
                 //    ahead of the path in the column it is about to look at.  Straight-line code, nothing indexed, no divergence.

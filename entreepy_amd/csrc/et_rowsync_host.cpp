@@ -4,7 +4,7 @@
 namespace et {
 
 bool row_code_of(const et_codebook *cb, RowCode *rc) {
-    if (!cb || !rc || cb->max_length != 8 || cb->min_length < 7) return false;
+    if (!cb || !rc || cb->min_length < 7 || cb->max_length > 8) return false;  // (7 / 7: 128 codewords of 7 bits, t = 128)
     bool seen7[128] = {}, seen8[256] = {};
     uint32_t n7 = 0, n8 = 0;
     for (int s = 0; s < 256; ++s) {

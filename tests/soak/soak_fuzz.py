@@ -27,8 +27,8 @@ def main():
             ctx.enable_timing(trial % 2 == 0)  # both launch flavours: with and without kernel-carried events
         n = int(rng.integers(20_000, max_bytes))
         src = int(rng.integers(0, 5))
-        if src == 4:  # flat alphabets of 129 .. 255 symbols: complete codes of 7 and 8 bits -- the row walk (csrc/et_rowsync.hip)
-            k = int(rng.integers(129, 256))
+        if src == 4:  # flat alphabets of 128 .. 255 symbols: complete codes of 7 and 8 bits -- the row walk (csrc/et_rowsync.hip)
+            k = int(rng.integers(128, 256)) if rng.integers(0, 8) else 128
             vals = (np.arange(k) + int(rng.integers(0, 257 - k))).astype(np.uint8)
             text = np.tile(vals, n // k + 1)[:n]
             rng.shuffle(text)

@@ -162,10 +162,34 @@ def test_declared_length_shorter_than_the_body(ctx):
     assert data.size <= m <= data.size + 1 and out[: data.size].cpu().numpy().tobytes() == data.tobytes()
 
 
-@pytest.mark.parametrize("t", [0, 1, 5, 64, 127])
+def test_128_equal_symbols_are_a_row_code_of_7_bit_codewords_only(ctx):
+    """The reference's builder on 128 symbols of equal weight: a complete tree of depth 7 -- t = 128, no 8-bit codeword at all;
+    every codeword moves the walk a column to the left and every eighth one wraps into the same row."""
+    import ctypes
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+
+    O = _oracle()
+    rng = np.random.default_rng(128)
+    data = np.repeat(rng.permutation(256)[:128].astype(np.uint8), 2500)
+    rng.shuffle(data)
+    want = O.encode(data.tobytes())
+    cb, n, off = E.parse_header(want[4:])
+    assert cb.raw.max_length == 7 and cb.raw.min_length == 7 and cb.raw.n_coded == 128
+    got_t = ctypes.c_uint32(999)
+    assert N.lib().et_row_code(ctypes.byref(cb.raw), ctypes.byref(got_t)) == N.ET_OK and got_t.value == 128
+    assert ctx.encode(data.tobytes()) == want
+    back, t = _timed_decode(ctx, want)
+    assert t["row_sync"] and t["exhaustive_sync"]
+    assert back == data.tobytes()
+
+
+@pytest.mark.parametrize("t", [0, 1, 5, 64, 127, 128])
 def test_hand_made_row_dictionaries(ctx, t):
     """Row codes that no encoder made: the 7-bit codewords 0 .. t-1 and the 8-bit codewords 2t .. 255 handed to symbols in random
-    order (t = 0: all 256 byte values with 8 bits each, which the reference's own encoder cannot produce -- it drops one of 256, Q1).
+    order (t = 0: all 256 byte values with 8 bits each, which the reference's own encoder cannot produce -- it drops one of 256, Q1;
+    t = 128: 128 symbols of 7 bits, every row a step to the left).
     The body is packed by the oracle with that table; the decode must return the text (the symbol table of the write pass is filled
     from the dictionary, not from an order the encoder would have used)."""
     import ctypes
@@ -255,7 +279,7 @@ def test_large_stream_many_chunks_in_flight(ctx):
         assert m == n and torch.equal(dec[:n], text)
 
 
-@pytest.mark.parametrize("k,ranks", [(255, 2), (255, 7), (200, 3), (130, 5)])
+@pytest.mark.parametrize("k,ranks", [(255, 2), (255, 7), (200, 3), (130, 5), (128, 3)])
 def test_ranges_of_a_stream_split_over_ranks(k, ranks):
     """et_decode_range_maps / _resolve / _write on a row code's stream cut into block ranges, each on its own et_ctx (what
     et_decode_sharded does on N GPUs): a range's MAP -- entry column -> the column the next range is entered in -- comes from one
