@@ -189,6 +189,8 @@ def measure_stream(torch, ctx, pipe, text, enc, dec, reps, lead, decode=True, ve
         out["kernels_only_round_trip_GBps"] = round(n / ((p["enc_total"] + p["dec_total"]) * 1e-3) / 1e9, 2)  # n / (enc_total + dec_total): begin of K1 .. end of K4 plus begin of D1 .. end of D3, instrumented steps
         if td.get("row_sync"):
             out["decode_path"] = "k_row_sync + k_row_write" if os.environ.get("ET_NO_ROW_WRITE") != "1" else "k_row_sync + k_dec_write_wave"
+        elif td.get("fixed_sync"):
+            out["decode_path"] = "k_fixed_write" if os.environ.get("ET_NO_FIXED_WRITE") != "1" else "k_fixed_sync + k_dec_write_wave"
         else:
             out["decode_path"] = ("exhaustive maps (k_dec_maps_reg / k_dec_compose / k_dec_chain / k_dec_resolve_reg)" if td["exhaustive_sync"]
                                   else ("k_tw_sync" if td["tree_walk_sync"] else "k_dec_sync_reg2")) + " + " + ("k_dec_write_wave" if td["chained_write"] else "k_dec_write_reg")

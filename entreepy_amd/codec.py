@@ -226,6 +226,7 @@ class Context:
         d["tree_walk_sync"] = bool(t.reserved & 2)
         d["chained_write"] = bool(t.reserved & 4)
         d["row_sync"] = bool(t.reserved & 8)
+        d["fixed_sync"] = bool(t.reserved & 16)
         return d
 
     def last_codebook(self):

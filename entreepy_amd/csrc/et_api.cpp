@@ -8,7 +8,8 @@
 //   header to pinned host memory (polled) -> host parse, the code as a tree + the chained tables' plan -> k_tw_build -> D1
 //   synchronisation by tree walk (one launch; repair sweeps only if the verification fails) -> D2 scan of the blocks' symbol counts
 //   (+ verification, report to the host) -> D3 write over chained tables.  Complete codes of 7- and 8-bit codewords (uniform-like
-//   bytes): k_row_sync -> D2 -> k_row_write (et_rowsync.h).  Anything outside those two walks' domains: et_kernels_fallback.hip.
+//   bytes): k_row_sync -> D2 -> k_row_write (et_rowsync.h); fixed-length codes (2^L codewords of L bits): k_fixed_write alone.
+//   Anything outside those domains: et_kernels_fallback.hip.
 // There is no CPU fallback anywhere in this file: without a usable HIP device every
 // entry point returns ET_ERR_HIP.
 #include "entreepy_hip.h"
@@ -1050,8 +1051,15 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     // instead of the exit maps for every start offset; the write then goes over the chained tables as for any full tree.
     et::RowCode row_code{};
     static const bool row_off = [] { const char *e = std::getenv("ET_NO_ROW_SYNC"); return e && e[0] == '1'; }();  // (A/B and the fallback's tests)
-    const bool row_sync = exhaustive && h_up && !row_off && et::row_code_of(cb, &row_code);
-    if (!tw_sweeps && !row_sync) ET_TRY(need_tables(true));
+    // Fixed-length codes (2^L codewords of L bits: four, 16, 64 symbols of about equal weight): where the codewords begin is arithmetic.
+    static const bool fixed_off = [] { const char *e = std::getenv("ET_NO_FIXED_SYNC"); return e && e[0] == '1'; }();  // (A/B and the fallback's tests)
+    const bool fixed_sync = exhaustive && h_up && !fixed_off && cb->min_length == cb->max_length && h_up->tree.n_int + 1 == cb->n_coded;
+    const bool row_sync = exhaustive && h_up && !fixed_sync && !row_off && et::row_code_of(cb, &row_code);
+    // ... and so is where symbol i lies: no synchronisation, no scan, no tables -- the write alone (k_fixed_write).  ET_NO_FIXED_WRITE=1 keeps
+    // k_fixed_sync's start / count words and the chained-table write behind them (A/B; what a range of such a stream on another GPU would take).
+    static const bool fixed_write_off = [] { const char *e = std::getenv("ET_NO_FIXED_WRITE"); return e && e[0] == '1'; }();
+    const bool fixed_direct = fixed_sync && !fixed_write_off && cb->max_length <= 8;
+    if (!tw_sweeps && !row_sync && !fixed_sync) ET_TRY(need_tables(true));
     const double t1 = now_ms();
 
     uint32_t *sub_state = static_cast<uint32_t *>(ctx->sub_state.p);
@@ -1099,6 +1107,12 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
             ET_HIP(hipGetLastError());
             return ET_OK;
         }
+        if (fixed_direct) {  // symbol i is the L bits at first_bit + i L (et_rowsync.h): no walk, no state
+            const et::KernelEvents ev = timed_body(ctx, EV_DEC + 2, EV_DEC + 3);
+            et::launch_fixed_write(ctx->stream, words, n_bytes, first_bit, cb, clamp, static_cast<uint8_t *>(d_out), ev.start, ev.stop);
+            ET_HIP(hipGetLastError());
+            return ET_OK;
+        }
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
                              write_ticket_zero, speculative ? flag : nullptr, timed_body(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain, cb->max_length);
         write_ticket_zero = false;
@@ -1107,7 +1121,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     };
     bool more_sweeps = false;
     // The synchronisation sweeps by tree walk and the write walk over chained lookup tables (no escapes).
-    if (h_up) {
+    if (h_up && !fixed_direct) {
         et::tw_chain_plan(&h_up->tree, &h_up->plan);
         ET_TRY(ensure(ctx, ctx->tw_tree, sizeof(et::TwUpload)));
         ET_TRY(ensure(ctx, ctx->chain_table, static_cast<size_t>(et::CH_MAX_ENTRIES) * sizeof(uint64_t)));
@@ -1118,7 +1132,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         }
         tw_n_int = h_up->tree.n_int;
         n_chain = h_up->plan.n_entries;
-        const bool zero_here = !flags_zeroed && (!exhaustive || row_sync);
+        const bool zero_here = !flags_zeroed && (!exhaustive || row_sync || fixed_sync);
         // (the kernel reads the tree and the plan from the pinned block itself: no upload in front of it)
         et::launch_tw_build(ctx->stream, h_up, static_cast<uint32_t>(et::tw_upload_bytes(h_up)), tw_n_int, tw_sweeps ? static_cast<uint16_t *>(ctx->tw_table.p) : nullptr, n_chain,
                             static_cast<uint64_t *>(ctx->chain_table.p), zero_here ? flag : nullptr, tw_sweeps ? static_cast<uint32_t *>(ctx->blk_pub.p) : nullptr, n_blocks);
@@ -1171,6 +1185,16 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         et::launch_row_sync(ctx->stream, words, n_bytes, first_bit, n_subs, row_code, ctx->row_scratch.p, flag + 3, sub_state, blk_exit, blk_count);
         ET_HIP(hipGetLastError());
         iters += 1;
+    } else if (exhaustive && fixed_sync) {
+        if (iters == 0) {
+            record(ctx, EV_DEC + 0);
+            record(ctx, EV_DEC + 5);
+        }
+        if (!fixed_direct) {
+            et::launch_fixed_sync(ctx->stream, n_bytes, first_bit, n_subs, cb->max_length, sub_state, blk_exit, blk_count);
+            ET_HIP(hipGetLastError());
+            iters += 1;
+        }
     } else if (exhaustive) {
         ET_TRY(need_tables(false));
         // The exhaustive kernels count with the older lookup tables, for which a bit pattern without a symbol is passed
@@ -1212,12 +1236,13 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         if (h_flags[0] == 0) break;
         if (iters > n_blocks + 4) return fail(ctx, ET_ERR_HIP, "decode synchronisation did not converge");
     }
-    if (exhaustive || more_sweeps) {
+    if ((exhaustive || more_sweeps) && !fixed_direct) {
         ET_TRY(scan_and_total(false));
         ET_TRY(wait_report());
         if (row_sync && h_flags[3] != 0) return fail(ctx, ET_ERR_HIP, "the row walk's chunks never saw the chunks before them");
     }
-    const uint64_t decodable = static_cast<uint64_t>(h_flags[12]) | (static_cast<uint64_t>(h_flags[13]) << 32);
+    const uint64_t decodable = fixed_direct ? (n_bytes * 8 >= first_bit ? (n_bytes * 8 - first_bit) / cb->max_length : 0)  // the whole codewords from first_bit on
+                                            : static_cast<uint64_t>(h_flags[12]) | (static_cast<uint64_t>(h_flags[13]) << 32);
     const uint64_t n_out = decodable < n_symbols ? decodable : n_symbols;
     if (n_out > cap) return fail(ctx, ET_ERR_CAP, "output buffer too small");
     if (n_out && !wrote) ET_TRY(write_symbols(n_out, false));
@@ -1226,7 +1251,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm_dec = et_timings{};
         ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
         ctx->tm_dec.sync_iters = iters;
-        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u);  // (row_sync: k_row_sync, and k_row_write unless ET_NO_ROW_WRITE)
+        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u) | (fixed_sync ? 16u : 0u);  // (row_sync: k_row_sync, and k_row_write unless ET_NO_ROW_WRITE; fixed_sync: k_fixed_sync)
         ctx->pend_dec = true;
         ctx->pend_dec_first = iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2);
         ctx->last_kind = 1;

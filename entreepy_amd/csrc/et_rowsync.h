@@ -59,5 +59,17 @@ void launch_row_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
                       const uint32_t *sub_state, const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr);
 
+// decode.zig:143-203 on a FIXED-length code -- 2^L codewords of L bits each (L <= 32): four symbols of about equal weight (a DNA
+// sequence), 16 (a hex dump), 64 (base64 of random bytes).  Nothing to walk: the k-th codeword begins at bit first_bit + k L, so a
+// subsequence's start, exit and count are three divisions (k_fixed_sync; outputs as launch_row_sync's).  A codeword cut by the
+// stream's end is nobody's, as everywhere.
+void launch_fixed_sync(hipStream_t stream, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, uint32_t code_bits, uint32_t *sub_state, uint32_t *blk_exit,
+                       uint32_t *blk_count);
+
+// The write pass for such a stream (k_fixed_write): symbol i is the code_bits bits at first_bit + i code_bits; n_out of them to out
+// (16-byte aligned) -- n_out <= the whole codewords the stream holds (callers clamp).  code_bits <= 8.
+void launch_fixed_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, const et_codebook *cb, uint64_t n_out, uint8_t *out,
+                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 }  // namespace et
 #endif

@@ -20,6 +20,7 @@
 // every lane reads its start off its prefix map.  The stream is read once; nothing but the results leaves the chip.
 // (A ticket, not the block index, orders the chunks: a chunk only ever waits for chunks with smaller tickets, and those were
 // taken by workgroups that are running.)
+// At the file's end: fixed-length codes (k_fixed_sync, k_fixed_write) -- the same family's other extreme, where nothing has to be found.
 #include "et_rowsync.h"
 
 #include <hip/hip_ext.h>
@@ -528,6 +529,52 @@ __global__ __launch_bounds__(64 * WAVES) void k_row_write(const uint32_t *__rest
 #undef RWR_ADDR
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+//   decode.zig:143-203 on a fixed-length code -> k_fixed_sync: where the codewords begin is arithmetic.
+namespace {
+struct FixedSpan {
+    uint32_t start, exit, count;
+};
+// The codewords that begin in bits [lo, hi) of a stream of n_bits whose k-th codeword begins at first_bit + k L: the offset of the
+// first of them, how many are whole (begin + L <= n_bits), and where the first one behind them begins, relative to hi -- or, if the
+// stream ends first, the stream's end (the rule of rs_slow_walk above and of walk_subsequence, et_kernels_fallback.hip).
+__device__ __forceinline__ FixedSpan fixed_span(uint64_t lo, uint64_t hi, uint64_t n_bits, uint32_t first_bit, uint32_t L) {
+    const uint64_t pos0 = lo <= first_bit ? first_bit : first_bit + (lo - first_bit + L - 1) / L * L;
+    uint64_t count = 0, next = pos0;
+    if (n_bits >= L && pos0 < hi) {
+        const uint64_t lim = hi - 1 < n_bits - L ? hi - 1 : n_bits - L;  // the last bit a whole codeword of this span can begin at
+        if (pos0 <= lim) {
+            count = (lim - pos0) / L + 1;
+            next = pos0 + count * L;
+        }
+    }
+    FixedSpan r;
+    r.start = static_cast<uint32_t>(pos0 - lo);
+    r.exit = next >= hi ? static_cast<uint32_t>(next - hi) : (n_bits > hi ? static_cast<uint32_t>(n_bits - hi) : 0u);
+    r.count = static_cast<uint32_t>(count);
+    return r;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_fixed_sync(uint64_t n_bits, uint32_t first_bit, uint64_t n_subs, uint32_t n_blocks, uint32_t L, uint32_t *__restrict__ sub_state,
+                                                    uint32_t *__restrict__ blk_exit, uint32_t *__restrict__ blk_count) {
+    for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const uint64_t s = static_cast<uint64_t>(b) * 256 + threadIdx.x;
+        const FixedSpan sp = fixed_span(s * 256, s * 256 + 256, n_bits, first_bit, L);
+        if (s < n_subs) sub_state[s] = (s == 0 ? first_bit : sp.start) | (sp.exit << 8) | (sp.count << 16);
+        if (threadIdx.x == 255) blk_exit[b] = sp.exit;
+        if (threadIdx.x == 0) blk_count[b] = fixed_span(s * 256, s * 256 + 65536, n_bits, first_bit, L).count;
+    }
+}
+
+void launch_fixed_sync(hipStream_t stream, uint64_t n_bytes, uint32_t first_bit, uint64_t n_subs, uint32_t code_bits, uint32_t *sub_state, uint32_t *blk_exit,
+                       uint32_t *blk_count) {
+    const uint32_t n_blocks = static_cast<uint32_t>((n_subs + 255) / 256);
+    if (!n_blocks) return;
+    const uint32_t grid = n_blocks < 16384u ? n_blocks : 16384u;
+    hipLaunchKernelGGL(k_fixed_sync, dim3(grid), dim3(256), 0, stream, n_bytes * 8, first_bit, n_subs, n_blocks, code_bits, sub_state, blk_exit, blk_count);
+}
+
 size_t row_sync_scratch_bytes(uint32_t n_blocks) {
     const size_t n_chunks = (static_cast<size_t>(n_blocks) + RS_CH - 1) / RS_CH;
     return n_chunks * sizeof(unsigned long long) + 64;  // the chunks' words, then: ticket (4 bytes), pad, the range's map (8 bytes at + 8)
@@ -583,6 +630,105 @@ void launch_row_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
                               n_symbols, out);
     else
         hipLaunchKernelGGL(k_row_write<WAVES>, dim3(grid), dim3(64 * WAVES), 0, stream, words, n_bytes, n_blocks, n_subs, first_bit, rc.t, lut, sub_state, blk_off, n_symbols, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+//   decode.zig:186 on a fixed-length code -> k_fixed_write: symbol i is the L bits at first_bit + i L, whoever decodes it.
+//
+// No walk, no state, no stage: a thread takes 16 symbols -- 16 L <= 128 bits, five words from wherever they begin, shifted so that
+// the first of them begins at bit 0 of the first, then 16 fields at offsets the compiler knows -- looks them up in the code's 2^L
+// byte table in LDS and stores 16 bytes.  The chained-table write is at its worst on these streams: every lane of a wavefront
+// yields the same number of symbols, so with L = 4 the lanes' regions of the stage begin 64 bytes apart and the byte stores of
+// half the wavefront fall on one bank, and with L = 2 a subsequence's 128 symbols do not fit the stage and it is walked twice.
+template <int L>
+__global__ __launch_bounds__(256) void k_fixed_write(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t first_bit, uint64_t n_out, const RowLut lut,
+                                                     uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[256];
+    if (threadIdx.x < 64) reinterpret_cast<uint32_t *>(smem)[threadIdx.x] = reinterpret_cast<const uint32_t *>(lut.sym)[threadIdx.x];
+    __syncthreads();
+    const uint32_t lds_lut = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((rwr_lds_u8 *)smem));
+    const uint64_t n_groups = (n_out + 15) / 16;
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; g < n_groups; g += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t bit = first_bit + g * (16 * L);
+        const uint64_t w0 = bit >> 5;
+        const uint32_t sh = static_cast<uint32_t>(bit & 31);
+        uint32_t W[5];
+        if ((w0 + 5) * 4 <= n_bytes) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) W[j] = __builtin_bswap32(words[w0 + j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) W[j] = __builtin_bswap32(rs_load_guarded(words, w0 + j, n_bytes));
+        }
+        uint32_t V[4];  // the 128 bits from `bit` on
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[j] = sh ? __builtin_amdgcn_alignbit(W[j], W[j + 1], 32u - sh) : W[j];
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                constexpr uint32_t mask = (1u << L) - 1u;
+                const int at = (4 * q + i) * L, k = at >> 5, r = at & 31;  // the field's L bits begin at bit r (from the top) of V[k]
+                uint32_t f;
+                if (r + L <= 32) f = (V[k] >> (32 - r - L)) & mask;
+                else f = __builtin_amdgcn_alignbit(V[k], V[k < 3 ? k + 1 : 3], 64 - r - L) & mask;
+                const uint32_t sym = *reinterpret_cast<const rwr_lds_u8 *>(static_cast<uintptr_t>(lds_lut + f));
+                packed |= sym << (8 * i);
+            }
+            o[q] = packed;
+        }
+        uint8_t *dst = out + g * 16;
+        if (g * 16 + 16 <= n_out) {
+            typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+            u32x4_nt v;
+            v.x = o[0], v.y = o[1], v.z = o[2], v.w = o[3];
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4_nt *>(dst));
+        } else {  // the declared count's last few
+            const uint32_t left = static_cast<uint32_t>(n_out - g * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (static_cast<uint32_t>(4 * q + i) < left) dst[4 * q + i] = static_cast<uint8_t>(o[q] >> (8 * i));
+        }
+    }
+}
+
+void launch_fixed_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint32_t first_bit, const et_codebook *cb, uint64_t n_out, uint8_t *out,
+                        hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (!n_out) return;
+    const uint32_t L = cb->max_length;
+    RowLut lut = {};
+    for (int s = 0; s < 256; ++s)
+        if (cb->length[s] == L) lut.sym[cb->data[s] & ((1u << L) - 1u)] = static_cast<uint8_t>(s);
+    static thread_local int seen_dev = -1, cus = 256;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != seen_dev) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        seen_dev = dev;
+    }
+    const uint64_t n_wg = ((n_out + 15) / 16 + 255) / 256;
+    const uint32_t grid = static_cast<uint32_t>(n_wg < static_cast<uint64_t>(cus) * 32 ? n_wg : static_cast<uint64_t>(cus) * 32);
+#define ET_FIXED_CASE(l_)                                                                                                                                  \
+    case l_:                                                                                                                                               \
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_fixed_write<l_>, dim3(grid), dim3(256), 0, stream, ev_start, ev_stop, 0, words, n_bytes, first_bit, n_out, lut, out); \
+        else hipLaunchKernelGGL(k_fixed_write<l_>, dim3(grid), dim3(256), 0, stream, words, n_bytes, first_bit, n_out, lut, out);                         \
+        break;
+    switch (L) {
+        ET_FIXED_CASE(1)
+        ET_FIXED_CASE(2)
+        ET_FIXED_CASE(3)
+        ET_FIXED_CASE(4)
+        ET_FIXED_CASE(5)
+        ET_FIXED_CASE(6)
+        ET_FIXED_CASE(7)
+        ET_FIXED_CASE(8)
+        default: break;  // (a complete fixed-length code over bytes has at most 256 codewords: callers check)
+    }
+#undef ET_FIXED_CASE
 }
 
 }  // namespace et

@@ -64,7 +64,7 @@ typedef struct et_timings {
     float sync_ms;      /* decode: everything in front of the write kernel (sweeps, verification, scan) */
     float total_ms;     /* begin of the first large kernel to the end of the last */
     uint32_t sync_iters;/* decode: synchronisation launches */
-    uint32_t reserved;  /* decode: bit 0 = the exhaustive synchronisation path ran, bit 1 = the sweeps ran as a tree walk, bit 2 = the write pass used the chained tables, bit 3 = synchronised (and, unless switched off, written) by rows: a complete code of 7- and 8-bit codewords, et_row_code */
+    uint32_t reserved;  /* decode: bit 0 = the exhaustive synchronisation path ran, bit 1 = the sweeps ran as a tree walk, bit 2 = the write pass used the chained tables, bit 3 = synchronised (and, unless switched off, written) by rows: a complete code of 7- and 8-bit codewords, et_row_code, bit 4 = a fixed-length code (2^L codewords of L bits): decoded by arithmetic, no synchronisation (csrc/et_rowsync.h, k_fixed_write) */
     float sync_first_ms;/* decode: the first synchronisation sweep alone (k_dec_sync<first>) */
     uint32_t pad_;
 } et_timings;
@@ -183,7 +183,9 @@ int et_chain_tables(const et_codebook *cb, uint64_t *table, size_t cap_entries, 
  * re-synchronises (decode.zig:143-203 has no trouble with it; a parallel decoder has).  When the 7-bit codewords are
  * the values 0 .. t-1, which is how encode.zig:82-138 hands them out, a decode synchronises such a stream in one pass by
  * rows (bytes) and columns (bit offsets): csrc/et_rowsync.h.  et_row_code: ET_OK and *t when `cb` is such a code,
- * ET_ERR_UNSUPPORTED otherwise (the exit maps for every start offset then, csrc/et_kernels_fallback.hip). */
+ * ET_ERR_UNSUPPORTED otherwise (the exit maps for every start offset then, csrc/et_kernels_fallback.hip).  (A code of
+ * 2^L codewords of L bits each -- t = 0 and t = 128 among them -- is decoded by arithmetic before either: symbol i is
+ * the L bits at first_bit + i L.) */
 int et_row_code(const et_codebook *cb, uint32_t *t);
 
 /* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */

@@ -29,6 +29,8 @@ def main():
         src = int(rng.integers(0, 5))
         if src == 4:  # flat alphabets of 128 .. 255 symbols: complete codes of 7 and 8 bits -- the row walk (csrc/et_rowsync.hip)
             k = int(rng.integers(128, 256)) if rng.integers(0, 8) else 128
+            if rng.integers(0, 4) == 0:  # ... and fixed-length codes: 4 .. 64 symbols (k_fixed_write)
+                k = 1 << int(rng.integers(2, 7))
             vals = (np.arange(k) + int(rng.integers(0, 257 - k))).astype(np.uint8)
             text = np.tile(vals, n // k + 1)[:n]
             rng.shuffle(text)

@@ -181,8 +181,24 @@ def test_128_equal_symbols_are_a_row_code_of_7_bit_codewords_only(ctx):
     assert N.lib().et_row_code(ctypes.byref(cb.raw), ctypes.byref(got_t)) == N.ET_OK and got_t.value == 128
     assert ctx.encode(data.tobytes()) == want
     back, t = _timed_decode(ctx, want)
-    assert t["row_sync"] and t["exhaustive_sync"]
+    assert t["fixed_sync"] and t["exhaustive_sync"]  # (a fixed-length code first of all: tests/test_gpu_fixedsync.py; by rows in the child below)
     assert back == data.tobytes()
+    code = (
+        "import numpy as np, entreepy_amd as E\n"
+        "from oracle import oracle as O\n"
+        "c = E.Context(0); c.enable_timing(True)\n"
+        "rng = np.random.default_rng(128)\n"
+        "d = np.repeat(rng.permutation(256)[:128].astype(np.uint8), 2500); rng.shuffle(d)\n"
+        "for cut in (0, 1, 7, 33):\n"
+        "    et = O.encode(d.tobytes())\n"
+        "    et = et[: len(et) - cut]\n"
+        "    assert c.decode(et[4:]) == O.decode(et[4:])\n"
+        "    t = c.timings('decode')\n"
+        "    assert t['row_sync'] and not t['fixed_sync'], t\n"
+        "print('ok')\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, ET_NO_FIXED_SYNC="1"), timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("t", [0, 1, 5, 64, 127, 128])
@@ -223,7 +239,8 @@ def test_hand_made_row_dictionaries(ctx, t):
             tm = ctx.timings("decode")
         finally:
             ctx.enable_timing(False)
-        assert tm["row_sync"] and m == text.size and out[:m].cpu().numpy().tobytes() == text.tobytes(), (t, start_bit)
+        # (t = 0 and t = 128 are fixed-length codes, which go by arithmetic: tests/test_gpu_fixedsync.py)
+        assert tm["fixed_sync" if t in (0, 128) else "row_sync"] and m == text.size and out[:m].cpu().numpy().tobytes() == text.tobytes(), (t, start_bit)
 
 
 def test_fuzzed_bodies_match_the_oracle(ctx):
