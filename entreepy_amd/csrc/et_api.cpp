@@ -1039,21 +1039,24 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         have_tables = true;
         return prepare_decode_tables(ctx, cb, &tb, &tb_write, zero_flags ? static_cast<uint32_t *>(ctx->flag.p) : nullptr, zero_flags ? &flags_zeroed : nullptr);
     };
-    // A (nearly) fixed-length code has nothing to re-synchronise on: do not even try.
-    bool exhaustive = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2;
+    // A (nearly) fixed-length code has little to re-synchronise on: unless its mix of L- and (L + 1)-bit codewords says otherwise
+    // (et::quick_to_synchronise; the sweep's own verdict still decides: blocks that gave up -> the exit maps), do not even try.
+    const bool near_fixed = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2 && !et::quick_to_synchronise(cb);
+    bool exhaustive = near_fixed;
     et::TwUpload *h_up = nullptr;
     {
         h_up = ctx->h_tw_tree[ctx->tw_turn ^= 1];  // two pinned blocks in turn, as prepare_decode_tables' (this call waits for its flags before it returns)
         if (et::tw_build_tree(cb, &h_up->tree, true) != ET_OK) h_up = nullptr;  // (bit patterns without a symbol become leaves that decode as byte 0)
     }
+    // Fixed-length codes (2^L codewords of L bits: two, four, 16, 64 symbols of about equal weight): where the codewords begin is arithmetic.
+    static const bool fixed_off = [] { const char *e = std::getenv("ET_NO_FIXED_SYNC"); return e && e[0] == '1'; }();  // (A/B and the fallback's tests)
+    const bool fixed_sync = h_up && !fixed_off && cb->n_coded >= 2 && cb->min_length == cb->max_length && h_up->tree.n_int + 1 == cb->n_coded;
+    if (fixed_sync) exhaustive = true;  // (two 1-bit codewords as well: nothing for the tree walk to find)
     const bool tw_sweeps = h_up && !exhaustive;
     // Uniform-like bytes (complete codes of 7 and 8 bits, BASELINE's worst case): one pass by rows and columns (et_rowsync.h)
     // instead of the exit maps for every start offset; the write then goes over the chained tables as for any full tree.
     et::RowCode row_code{};
     static const bool row_off = [] { const char *e = std::getenv("ET_NO_ROW_SYNC"); return e && e[0] == '1'; }();  // (A/B and the fallback's tests)
-    // Fixed-length codes (2^L codewords of L bits: four, 16, 64 symbols of about equal weight): where the codewords begin is arithmetic.
-    static const bool fixed_off = [] { const char *e = std::getenv("ET_NO_FIXED_SYNC"); return e && e[0] == '1'; }();  // (A/B and the fallback's tests)
-    const bool fixed_sync = exhaustive && h_up && !fixed_off && cb->min_length == cb->max_length && h_up->tree.n_int + 1 == cb->n_coded;
     const bool row_sync = exhaustive && h_up && !fixed_sync && !row_off && et::row_code_of(cb, &row_code);
     // ... and so is where symbol i lies: no synchronisation, no scan, no tables -- the write alone (k_fixed_write).  ET_NO_FIXED_WRITE=1 keeps
     // k_fixed_sync's start / count words and the chained-table write behind them (A/B; what a range of such a stream on another GPU would take).
@@ -1253,7 +1256,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm_dec.sync_iters = iters;
         ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u) | (fixed_sync ? 16u : 0u);  // (row_sync: k_row_sync, and k_row_write unless ET_NO_ROW_WRITE; fixed_sync: k_fixed_sync)
         ctx->pend_dec = true;
-        ctx->pend_dec_first = iters > 0 && !(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2);
+        ctx->pend_dec_first = iters > 0 && !near_fixed && !fixed_sync;
         ctx->last_kind = 1;
     }
     return ET_OK;

@@ -14,7 +14,7 @@ from tests.test_gpu_rowsync import _oracle, _timed_decode, flat
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k", [4, 8, 16, 32, 64, 128])
+@pytest.mark.parametrize("k", [2, 4, 8, 16, 32, 64, 128])
 def test_power_of_two_alphabets_decode_by_arithmetic(ctx, k):
     """The reference's builder on 2^L symbols of equal weight gives 2^L codewords of L bits; .et images equal the oracle's,
     the decode takes k_fixed_sync and k_fixed_write."""
@@ -32,18 +32,33 @@ def test_power_of_two_alphabets_decode_by_arithmetic(ctx, k):
     assert back == data.tobytes()
 
 
-def test_two_symbols_and_almost_flat_alphabets_take_their_own_paths(ctx):
-    """k = 2 (1-bit codes) re-synchronises trivially and stays with the tree walk; 10 symbols (3 and 4 bits) are not a fixed-length
-    code: the exit maps."""
+@pytest.mark.parametrize("k,quick", [(3, True), (6, True), (10, True), (17, True), (26, True), (36, True), (50, True), (100, True), (31, False), (62, False), (120, False), (65, False)])
+def test_codes_of_two_lengths_try_the_tree_walk_when_they_settle_quickly(ctx, k, quick):
+    """k symbols of equal weight, k not a power of two: codewords of L and L + 1 bits.  Most such codes re-synchronise within the tree
+    walk's reach (et::quick_to_synchronise estimates it from the share of short codewords) and decode like text; those with a lone short
+    or long codeword among many (k = 2^L + 1, 2^(L+1) - 1) do not and go to the exit maps at once.  Either way: the oracle's bytes."""
     O = _oracle()
-    for k, want_fixed in ((2, False), (10, False), (16, True)):
+    data = flat(k, 600_011, 300 + k)
+    et = O.encode(data.tobytes())
+    assert ctx.encode(data.tobytes()) == et
+    back, t = _timed_decode(ctx, et)
+    assert back == data.tobytes()
+    assert t["tree_walk_sync"] == quick and t["exhaustive_sync"] == (not quick), t
+    for cut in (1, 3, 8190, 8200):
+        assert ctx.decode(et[4:-cut]) == O.decode(et[4:-cut]), cut
+
+
+def test_almost_flat_alphabets_take_their_own_paths(ctx):
+    """10 symbols (3 and 4 bits) or 3 (1 and 2 bits) are not a fixed-length code: the exit maps / the tree walk."""
+    O = _oracle()
+    for k, want_fixed in ((3, False), (10, False), (16, True)):
         data = flat(k, 100_003, k)
         et = O.encode(data.tobytes())
         back, t = _timed_decode(ctx, et)
         assert back == data.tobytes() and t["fixed_sync"] == want_fixed, k
 
 
-@pytest.mark.parametrize("L", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 6, 7])
 def test_sizes_start_bits_and_alignments(ctx, L):
     """Bodies packed by the oracle from any start bit and byte alignment, ending everywhere around a subsequence and a block
     (L = 3, 5, 6: a codeword straddles the subsequences' seams at a different offset in every one of them)."""
@@ -194,12 +209,13 @@ def test_fallbacks_still_decode_these_streams(switch):
         "from tests.test_gpu_rowsync import flat\n"
         "from oracle import oracle as O\n"
         "c = E.Context(0); c.enable_timing(True)\n"
-        "for k in (4, 16, 64):\n"
-        "    d = flat(k, 200_003, k)\n"
+        "for k in (2, 4, 16, 64):\n"
+        "    d = flat(k, 200_003 if k > 2 else 3_000_001, k)  # (1-bit codes: blocks of 65 536 symbols, four windows of the chained write's stage each)\n"
         "    et = O.encode(d.tobytes())\n"
         "    assert c.decode(et[4:]) == d.tobytes()\n"
         "    t = c.timings('decode')\n"
-        "    assert t['exhaustive_sync'] and t['fixed_sync'] == (SWITCH == 'ET_NO_FIXED_WRITE'), t\n"
+        "    assert t['fixed_sync'] == (SWITCH == 'ET_NO_FIXED_WRITE'), t\n"
+        "    assert t['exhaustive_sync'] == (k != 2 or t['fixed_sync']), t  # (two 1-bit codewords without the arithmetic: the tree walk)\n"
         "    for cut in (1, 2, 9):\n"
         "        assert c.decode(et[4:-cut]) == O.decode(et[4:-cut])\n"
         "print('ok')\n"

@@ -822,7 +822,8 @@ def test_chained_write_windows_and_long_codes(ctx):
             comp = torch.frombuffer(bytearray(et[4:]), dtype=torch.uint8).cuda()
             out = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
             assert ctx.decode_device(comp, out) == data.size
-            assert ctx.timings("decode")["chained_write"]
+            t = ctx.timings("decode")
+            assert t["chained_write"] or t["fixed_sync"]  # (two 1-bit codewords go by arithmetic since round 4: the windows of such a block, tests/test_gpu_fixedsync.py's ET_NO_FIXED_SYNC child)
             assert out[: data.size].cpu().numpy().tobytes() == data.tobytes()
             for cut in (1, 2, 3, 5, 64, 257, 8191, 8200):  # truncated bodies: whatever the oracle makes of them
                 short = et[4 : len(et) - cut]
