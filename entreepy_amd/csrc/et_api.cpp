@@ -1041,7 +1041,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     };
     // A (nearly) fixed-length code has little to re-synchronise on: unless its mix of L- and (L + 1)-bit codewords says otherwise
     // (et::quick_to_synchronise; the sweep's own verdict still decides: blocks that gave up -> the exit maps), do not even try.
-    const bool near_fixed = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2 && !et::quick_to_synchronise(cb);
+    static const bool quick_off = [] { const char *e = std::getenv("ET_NO_QUICK_SYNC"); return e && e[0] == '1'; }();  // (A/B and the tests of the paths behind it)
+    const bool near_fixed = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2 && (quick_off || !et::quick_to_synchronise(cb));
     bool exhaustive = near_fixed;
     et::TwUpload *h_up = nullptr;
     {
@@ -1057,7 +1058,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     // instead of the exit maps for every start offset; the write then goes over the chained tables as for any full tree.
     et::RowCode row_code{};
     static const bool row_off = [] { const char *e = std::getenv("ET_NO_ROW_SYNC"); return e && e[0] == '1'; }();  // (A/B and the fallback's tests)
-    const bool row_sync = exhaustive && h_up && !fixed_sync && !row_off && et::row_code_of(cb, &row_code);
+    const bool row_ok = h_up && !fixed_sync && !row_off && et::row_code_of(cb, &row_code);
+    bool row_sync = exhaustive && row_ok;  // (also where a row code that tried the tree walk ends up if its blocks give up, below)
     // ... and so is where symbol i lies: no synchronisation, no scan, no tables -- the write alone (k_fixed_write).  ET_NO_FIXED_WRITE=1 keeps
     // k_fixed_sync's start / count words and the chained-table write behind them (A/B; what a range of such a stream on another GPU would take).
     static const bool fixed_write_off = [] { const char *e = std::getenv("ET_NO_FIXED_WRITE"); return e && e[0] == '1'; }();
@@ -1176,6 +1178,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         }
         ET_TRY(wait_report());  // not the stream: the write kernel keeps running while the caller moves on
         exhaustive = static_cast<uint64_t>(h_flags[1]) * 64 > n_blocks;
+        row_sync = exhaustive && row_ok;
         more_sweeps = !exhaustive && h_flags[2] != 0;
         if (!et::dec_state_final(h_flags[1], h_flags[2], n_blocks)) wrote = false;  // the speculative launch declined by the same rule
     }

@@ -26,7 +26,7 @@ struct RowCode {
 // true when cb is such a code: lengths 7 and 8 only (or 7 only: 128 codewords, t = 128), complete (2 * n7 + n8 = 256), prefix-free, the 7-bit codes are the
 // values 0 .. n7-1.  (No HIP in this function: et_rowsync_host.cpp compiles with plain g++.)
 bool row_code_of(const et_codebook *cb, RowCode *rc);
-// true when cb is a code of L- and (L + 1)-bit codewords, L < 7, that re-synchronises within the tree walk's reach all the same
+// true when cb is a code of L- and (L + 1)-bit codewords, L <= 7, that re-synchronises within the tree walk's reach all the same
 // (most of them do: et_rowsync_host.cpp): the decode then tries the tree walk first instead of going to the exit maps at once.
 bool quick_to_synchronise(const et_codebook *cb);
 

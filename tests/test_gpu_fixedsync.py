@@ -32,7 +32,7 @@ def test_power_of_two_alphabets_decode_by_arithmetic(ctx, k):
     assert back == data.tobytes()
 
 
-@pytest.mark.parametrize("k,quick", [(3, True), (6, True), (10, True), (17, True), (26, True), (36, True), (50, True), (100, True), (31, False), (62, False), (120, False), (65, False)])
+@pytest.mark.parametrize("k,quick", [(3, True), (6, True), (10, True), (17, True), (26, True), (36, True), (50, True), (100, True), (31, False), (62, False), (120, False), (65, False), (160, True), (200, True), (136, False), (240, False)])
 def test_codes_of_two_lengths_try_the_tree_walk_when_they_settle_quickly(ctx, k, quick):
     """k symbols of equal weight, k not a power of two: codewords of L and L + 1 bits.  Most such codes re-synchronise within the tree
     walk's reach (et::quick_to_synchronise estimates it from the share of short codewords) and decode like text; those with a lone short

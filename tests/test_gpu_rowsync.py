@@ -41,10 +41,12 @@ def _timed_decode(ctx, et):
     return back, t
 
 
-@pytest.mark.parametrize("k", [129, 130, 160, 200, 240, 250, 254, 255])
+@pytest.mark.parametrize("k", [129, 130, 135, 139, 215, 240, 250, 254, 255])
 def test_flat_alphabets_decode_by_rows(ctx, k):
-    """T = 256 - k seven-bit codes, from 127 down to 1: every share of short codes, paths that change column at
-    almost every row and paths that never do."""
+    """T = 256 - k seven-bit codes, from 127 down to 1: paths that change column at almost every row and paths that never do.
+    (Between ~140 and ~210 symbols such a code settles quickly enough for the tree walk, which is then the faster one:
+    tests/test_gpu_fixedsync.py::test_codes_of_two_lengths_...; the row walk on those alphabets: the hand-made t = 64 below behind
+    ET_NO_ROW_SYNC's sibling switch, test_row_walk_on_codes_the_tree_walk_would_take.)"""
     import entreepy_amd as E
 
     O = _oracle()
@@ -240,7 +242,8 @@ def test_hand_made_row_dictionaries(ctx, t):
         finally:
             ctx.enable_timing(False)
         # (t = 0 and t = 128 are fixed-length codes, which go by arithmetic: tests/test_gpu_fixedsync.py)
-        assert tm["fixed_sync" if t in (0, 128) else "row_sync"] and m == text.size and out[:m].cpu().numpy().tobytes() == text.tobytes(), (t, start_bit)
+        # (... and t = 64 -- half of the 7-bit patterns are codewords -- settles within the tree walk's reach, which takes it)
+        assert tm["fixed_sync" if t in (0, 128) else ("tree_walk_sync" if t == 64 else "row_sync")] and m == text.size and out[:m].cpu().numpy().tobytes() == text.tobytes(), (t, start_bit)
 
 
 def test_fuzzed_bodies_match_the_oracle(ctx):
@@ -342,6 +345,28 @@ def test_ranges_of_a_stream_split_over_ranks(k, ranks):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_row_walk_on_codes_the_tree_walk_would_take():
+    """ET_NO_QUICK_SYNC=1 (a child process): 160 and 200 symbols -- t = 96 and 56 seven-bit codewords, paths that change column
+    every few rows -- by rows, as before the decode learnt to try the tree walk on them."""
+    code = (
+        "import numpy as np, entreepy_amd as E\n"
+        "from tests.test_gpu_rowsync import flat\n"
+        "from oracle import oracle as O\n"
+        "c = E.Context(0); c.enable_timing(True)\n"
+        "for k in (160, 200):\n"
+        "    d = flat(k, 400_003, k)\n"
+        "    et = O.encode(d.tobytes())\n"
+        "    assert c.decode(et[4:]) == d.tobytes()\n"
+        "    t = c.timings('decode')\n"
+        "    assert t['row_sync'] and not t['tree_walk_sync'], t\n"
+        "    for cut in (1, 5, 8191):\n"
+        "        assert c.decode(et[4:-cut]) == O.decode(et[4:-cut])\n"
+        "print('ok')\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, ET_NO_QUICK_SYNC="1"), timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("switch", ["ET_NO_ROW_SYNC", "ET_NO_ROW_WRITE"])
