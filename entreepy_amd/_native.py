@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("ET_LIB_PATH") or os.path.join(_HERE, "libentreepy_hip
 
 ET_OK, ET_ERR_EMPTY, ET_ERR_NOMEM, ET_ERR_CAP, ET_ERR_FORMAT, ET_ERR_HIP, ET_ERR_ARG, ET_ERR_UNSUPPORTED, ET_ERR_IO, ET_ERR_RCCL = range(10)
 ET_RCCL_ID_BYTES = 128
+ET_PATH_TREE_WALK, ET_PATH_EXIT_MAPS, ET_PATH_ROWS, ET_PATH_FIXED, ET_PATH_WINDOWS = range(5)  # et_decode_path
 
 
 class Codebook(ctypes.Structure):
@@ -104,6 +105,7 @@ SIGNATURES = {
     "et_selftest_treewalk_table": (ctypes.c_int, [_vp, _cbp, ctypes.POINTER(ctypes.c_uint32)]),
     "et_chain_tables": (ctypes.c_int, [_cbp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), _vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "et_row_code": (ctypes.c_int, [_cbp, ctypes.POINTER(ctypes.c_uint32)]),
+    "et_decode_path": (ctypes.c_int, [_cbp, ctypes.POINTER(ctypes.c_uint32)]),
     "et_encode_bound": (_sz, [_sz]),
     "et_encode_fd": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "et_decode_fd": (ctypes.c_int, [_vp, ctypes.c_int, _sz, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),

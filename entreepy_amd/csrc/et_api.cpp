@@ -999,6 +999,22 @@ extern "C" int et_row_code(const et_codebook *cb, uint32_t *t) {
     return ET_OK;
 }
 
+// Which way a one-GPU decode of a whole stream goes for this code table, before it has seen the stream (et_decode_body_device makes
+// the same choices in the same order -- tests/test_gpu_fixedsync.py holds the two against each other; the switches ET_NO_* aside).
+extern "C" int et_decode_path(const et_codebook *cb, uint32_t *path) {
+    if (!cb || !path) return ET_ERR_ARG;
+    if (cb->n_coded == 0) return ET_ERR_ARG;
+    if (cb->max_length > 32) return ET_ERR_UNSUPPORTED;
+    et::TwTree tree;
+    const bool have_tree = et::tw_build_tree(cb, &tree, true) == ET_OK;
+    et::RowCode rc{};
+    if (!have_tree) *path = ET_PATH_WINDOWS;
+    else if (cb->n_coded >= 2 && cb->min_length == cb->max_length && tree.n_int + 1 == cb->n_coded) *path = ET_PATH_FIXED;
+    else if (!(cb->max_length <= cb->min_length + 1 && cb->n_coded > 2) || et::quick_to_synchronise(cb)) *path = ET_PATH_TREE_WALK;
+    else *path = et::row_code_of(cb, &rc) ? ET_PATH_ROWS : ET_PATH_EXIT_MAPS;
+    return ET_OK;
+}
+
 extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const void *d_body, size_t body_bytes, uint32_t start_bit,
                                      uint64_t n_symbols, void *d_out, size_t cap, size_t *out_len) {
     if (!ctx || !cb || !out_len) return ET_ERR_ARG;

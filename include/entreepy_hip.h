@@ -188,6 +188,17 @@ int et_chain_tables(const et_codebook *cb, uint64_t *table, size_t cap_entries, 
  * the L bits at first_bit + i L.) */
 int et_row_code(const et_codebook *cb, uint32_t *t);
 
+/* Which synchronisation a one-GPU decode of a whole stream starts with for this code table (diagnostics; decode.zig:143-203
+ * needs no such choice -- one thread walks the stream).  The stream itself can still overrule the first two: blocks that do
+ * not settle under the tree walk go to the exit maps, or by rows if the code is a row code.
+ *   ET_PATH_TREE_WALK  the tree walk (text, and codes of L and L + 1 bits whose mix of lengths settles quickly: csrc/et_rowsync_host.cpp)
+ *   ET_PATH_EXIT_MAPS  exit maps for every start offset (near-fixed-length codes that do not settle; csrc/et_kernels_fallback.hip)
+ *   ET_PATH_ROWS       by byte rows and bit columns (complete codes of 7 and 8 bits that do not settle: uniform bytes; et_row_code)
+ *   ET_PATH_FIXED      2^L codewords of L bits: no synchronisation, symbol i is the L bits at first_bit + i L
+ *   ET_PATH_WINDOWS    the round-1 window kernels (a dictionary whose completed tree has more than 255 internal nodes or is not prefix-free) */
+enum { ET_PATH_TREE_WALK = 0, ET_PATH_EXIT_MAPS = 1, ET_PATH_ROWS = 2, ET_PATH_FIXED = 3, ET_PATH_WINDOWS = 4 };
+int et_decode_path(const et_codebook *cb, uint32_t *path);
+
 /* Header field "length of body" (decode.zig:36-42) so callers can size `out`. */
 int et_decoded_size(const uint8_t *compressed, size_t len, size_t *n_symbols);
 

@@ -44,6 +44,16 @@ def test_codes_of_two_lengths_try_the_tree_walk_when_they_settle_quickly(ctx, k,
     back, t = _timed_decode(ctx, et)
     assert back == data.tobytes()
     assert t["tree_walk_sync"] == quick and t["exhaustive_sync"] == (not quick), t
+    # ... and et_decode_path, the diagnostic, says what ran
+    import ctypes
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+
+    cb, _, _ = E.parse_header(et[4:])
+    p = ctypes.c_uint32(99)
+    assert N.lib().et_decode_path(ctypes.byref(cb.raw), ctypes.byref(p)) == N.ET_OK
+    assert p.value == (N.ET_PATH_TREE_WALK if quick else (N.ET_PATH_ROWS if t["row_sync"] else N.ET_PATH_EXIT_MAPS))
     for cut in (1, 3, 8190, 8200):
         assert ctx.decode(et[4:-cut]) == O.decode(et[4:-cut]), cut
 

@@ -428,3 +428,40 @@ def test_row_code_is_the_flat_codes_of_the_reference_builder_only():
     from tests import corpus
 
     assert row_t(E.Codebook.from_histogram(np.bincount(corpus.text_like(100_000, 1), minlength=256))) is None
+
+
+def test_decode_path_of_flat_alphabets():
+    """et_decode_path (diagnostics): which synchronisation a one-GPU decode starts with, from the code table alone.  k symbols of
+    equal weight through the reference's builder: powers of two are fixed-length codes; codes of L and L + 1 bits take the tree
+    walk when et::quick_to_synchronise expects them to settle -- the table below is what the GPU runs measured
+    (profiles/r04_flat_alphabets.jsonl: the tree walk settles the 'T' rows, most blocks give up on the others) -- and the exit
+    maps or, with 7 and 8 bits, the row walk when not; text takes the tree walk."""
+    import ctypes
+
+    import entreepy_amd as E
+    from entreepy_amd import _native as N
+    from tests import corpus
+
+    def path(cb):
+        p = ctypes.c_uint32(99)
+        assert N.lib().et_decode_path(ctypes.byref(cb.raw), ctypes.byref(p)) == N.ET_OK
+        return "TMRFW"[p.value]
+
+    def flat_code(k):
+        h = np.zeros(256, dtype=np.uint64)
+        h[:k] = 1000
+        return E.Codebook.from_histogram(h)
+
+    want = {2: "F", 3: "T", 4: "F", 5: "T", 7: "T", 8: "F", 10: "T", 14: "T", 16: "F", 17: "T", 26: "T", 30: "T", 31: "M", 32: "F", 33: "M", 34: "T", 36: "T", 50: "T", 58: "T",
+            60: "T", 61: "M", 62: "M", 64: "F", 65: "M", 68: "T", 72: "T", 100: "T", 112: "T", 120: "M", 124: "M", 128: "F", 129: "R", 136: "R", 150: "T", 160: "T",
+            200: "T", 205: "T", 215: "R", 240: "R", 254: "R", 255: "R"}
+    got = {k: path(flat_code(k)) for k in want}
+    assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+    assert path(E.Codebook.from_histogram(np.bincount(corpus.text_like(100_000, 1), minlength=256))) == "T"
+    two = np.zeros(256, dtype=np.uint64)
+    two[65], two[66] = 1000, 3
+    assert path(E.Codebook.from_histogram(two)) == "F"  # two codewords of one bit, however skewed
+    # hand-made: 256 codewords of 8 bits (fixed), the same less one (not complete: not fixed, and no row code either)
+    assert path(E.Codebook.from_tables(np.arange(256, dtype=np.uint32), np.full(256, 8, dtype=np.uint8))) == "F"
+    assert path(E.Codebook.from_tables(np.arange(256, dtype=np.uint32), np.where(np.arange(256) < 255, 8, 0).astype(np.uint8))) == "M"
+
