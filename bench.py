@@ -198,7 +198,7 @@ def measure_stream(torch, ctx, pipe, text, enc, dec, reps, lead, decode=True, ve
     return out
 
 
-EXTRA_WORKLOADS = ("enwik-like", "text-100M", "text-5M", "uniform255-4G", "uniform256-16G")
+EXTRA_WORKLOADS = ("enwik-like", "text-100M", "text-5M", "flat4-1G", "flat10-1G", "flat26-1G", "uniform255-4G", "uniform256-16G")
 
 
 def run_extra_workload(name, torch, E, corpus, ctx, pipe, dev, n_headline, verify=True, reps=None):
@@ -240,6 +240,13 @@ def run_extra_workload(name, torch, E, corpus, ctx, pipe, dev, n_headline, verif
         what = (f"uniform256-16G: {n} B uniform over all 256 byte values, seed 0x5EED0005 (BASELINE configs[4]), encode only: with 256 distinct "
                 f"values the reference's encoder drops a symbol (Q1) and the stream has no inverse")
         reps, lead, decode = reps or 5, 2, False
+    elif name in ("flat4-1G", "flat10-1G", "flat26-1G"):  # not BASELINE configurations: the small flat alphabets next to its worst case (DNA-, digit-, letter-like)
+        k = int(name[4 : name.index("-")])
+        n = n_headline
+        text = uniform_bytes_torch(n, 48, 48 + k, 0x5EED0F00 + k, dev)
+        what = (f"{name}: {n} B uniform over {k} byte values, seed {0x5EED0F00 + k:#x} (not a BASELINE configuration: the small flat alphabets beside configs[4]); "
+                + ("2-bit codewords only: decoded by arithmetic, no synchronisation" if k == 4 else "codes of two neighbouring lengths that settle quickly: the tree walk"))
+        reps, lead, decode = reps or 10, 10, True
     else:
         return {"error": f"unknown workload {name}"}
     n = text.numel()
