@@ -1058,7 +1058,8 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
     // A (nearly) fixed-length code has little to re-synchronise on: unless its mix of L- and (L + 1)-bit codewords says otherwise
     // (et::quick_to_synchronise; the sweep's own verdict still decides: blocks that gave up -> the exit maps), do not even try.
     static const bool quick_off = [] { const char *e = std::getenv("ET_NO_QUICK_SYNC"); return e && e[0] == '1'; }();  // (A/B and the tests of the paths behind it)
-    const bool near_fixed = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2 && (quick_off || !et::quick_to_synchronise(cb));
+    static const bool quick_always = [] { const char *e = std::getenv("ET_QUICK_SYNC_ALWAYS"); return e && e[0] == '1'; }();  // (tools/probe/ab_flat_rule.sh: where does the tree walk stop settling?)
+    const bool near_fixed = cb->max_length <= cb->min_length + 1 && cb->n_coded > 2 && !quick_always && (quick_off || !et::quick_to_synchronise(cb));
     bool exhaustive = near_fixed;
     et::TwUpload *h_up = nullptr;
     {
