@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Round trip of 256 MiB streams of one, two and three byte values (bench.measure_stream): a lone symbol encodes to the bare header
+(the reference's Q2: no inverse -- bench.fail says so and the line shows "exit"), two values are two 1-bit codewords (k_fixed_write),
+three with two of them rare put ~250 symbols into a 256-bit subsequence (the chained write's windows: DESIGN section 7, 3b).
+    python3 tools/probe/degenerate_streams.py      -> one JSON line per case"""
 import json, os, sys
 sys.path.insert(0, os.getcwd())
 import torch, bench
