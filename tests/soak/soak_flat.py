@@ -3,7 +3,7 @@ or nearly so (every code of one or two neighbouring lengths: fixed-length -> k_f
 et::quick_to_synchronise says so, else the exit maps; 7 and 8 bits -> the row walk), streams of 1 KB .. MAX_BYTES, encoded and
 decoded on the device and compared there; every 4th trial also decodes a truncated copy and holds it against the oracle (small
 streams only).  Whatever the first sweep makes of a stream that does not settle, the result must be the text.
-Usage: python tests/soak/soak_flat.py SEED TRIALS [MAX_BYTES]"""
+Usage: python tests/soak/soak_flat.py SEED TRIALS [MAX_BYTES [MIN_BYTES]]"""
 import os
 import sys
 import time
@@ -19,6 +19,7 @@ from oracle import oracle as O
 def main():
     seed, trials = int(sys.argv[1]), int(sys.argv[2])
     max_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 24_000_000
+    min_bytes = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
     ctx = E.Context(0)
     ctx.use_torch_stream()
     ctx.enable_timing(True)
@@ -32,7 +33,7 @@ def main():
     dec = torch.empty(max_bytes + 64, dtype=torch.uint8, device="cuda")
     for trial in range(trials):
         k = int(rng.integers(2, 256))
-        n = int(10 ** rng.uniform(3, np.log10(max_bytes)))
+        n = int(10 ** rng.uniform(np.log10(min_bytes), np.log10(max_bytes)))
         lo = int(rng.integers(0, 257 - k))
         if rng.integers(0, 3) == 0:  # weights within a factor of ~1.5 of each other: still one or two neighbouring lengths, other codes
             w = torch.from_numpy(rng.uniform(1.0, 1.5, size=k)).cuda()
