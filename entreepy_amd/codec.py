@@ -227,6 +227,7 @@ class Context:
         d["chained_write"] = bool(t.reserved & 4)
         d["row_sync"] = bool(t.reserved & 8)
         d["fixed_sync"] = bool(t.reserved & 16)
+        d["strips_write"] = bool(t.reserved & 32)
         return d
 
     def last_codebook(self):

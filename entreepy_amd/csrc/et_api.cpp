@@ -1120,6 +1120,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ET_HIP(hipGetLastError());
         return ET_OK;
     };
+    bool used_strips = false;
     auto write_symbols = [&](uint64_t clamp, bool speculative) -> int {
         // speculative: the kernel itself looks at the sweeps' flags and does nothing if the state is not final
         static const bool row_write_off = [] { const char *e = std::getenv("ET_NO_ROW_WRITE"); return e && e[0] == '1'; }();  // (A/B: the chained-table write on a row code's stream)
@@ -1135,8 +1136,14 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
             ET_HIP(hipGetLastError());
             return ET_OK;
         }
+        // More than 128 symbols per 256-bit subsequence (the header says how many symbols the body's bits hold): a quarter's output is three or more
+        // windows of the write's 4 KiB stage, i.e. it would be walked three or more times -- the instantiation that walks it once, into strips
+        // (measured: +45 % at 140 symbols per subsequence, +75 % at 200; at 90-110, two windows, the strips' scattered stores cost what they save).
+        static const bool strips_off = [] { const char *e = std::getenv("ET_NO_STRIPS"); return e && e[0] == '1'; }();  // (A/B and the windows' tests)
+        const bool strips = !strips_off && chain && n_symbols / 128 > n_subs;
+        used_strips = used_strips || strips;
         et::launch_dec_write(ctx->stream, words, n_bytes, n_subs, tb_write, sub_state, blk_off, clamp, static_cast<uint8_t *>(d_out), flag + 5, side,
-                             write_ticket_zero, speculative ? flag : nullptr, timed_body(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain, cb->max_length);
+                             write_ticket_zero, speculative ? flag : nullptr, timed_body(ctx, EV_DEC + 2, EV_DEC + 3), chain, n_chain, cb->max_length, strips);
         write_ticket_zero = false;
         ET_HIP(hipGetLastError());
         return ET_OK;
@@ -1274,7 +1281,7 @@ extern "C" int et_decode_body_device(et_ctx *ctx, const et_codebook *cb, const v
         ctx->tm_dec = et_timings{};
         ctx->tm_dec.host_ms = static_cast<float>(t1 - t0);
         ctx->tm_dec.sync_iters = iters;
-        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u) | (fixed_sync ? 16u : 0u);  // (row_sync: k_row_sync, and k_row_write unless ET_NO_ROW_WRITE; fixed_sync: k_fixed_sync)
+        ctx->tm_dec.reserved = (exhaustive ? 1u : 0u) | (tw_table ? 2u : 0u) | (chain ? 4u : 0u) | (row_sync ? 8u : 0u) | (fixed_sync ? 16u : 0u) | (used_strips ? 32u : 0u);  // (row_sync: k_row_sync, and k_row_write unless ET_NO_ROW_WRITE; fixed_sync: k_fixed_sync)
         ctx->pend_dec = true;
         ctx->pend_dec_first = iters > 0 && !near_fixed && !fixed_sync;
         ctx->last_kind = 1;

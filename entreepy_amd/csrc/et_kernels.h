@@ -130,6 +130,7 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side = nullptr,
                       bool ticket_is_zero = false, const uint32_t *void_flags = nullptr, KernelEvents ev = {},  // ev: the main write kernel
-                      const uint64_t *chain = nullptr, uint32_t n_chain = 0, uint32_t chain_max_len = 32);  // chained lookup tables (et_treewalk.h) and the dictionary's longest code: every block by k_dec_write_wave
+                      const uint64_t *chain = nullptr, uint32_t n_chain = 0, uint32_t chain_max_len = 32,  // chained lookup tables (et_treewalk.h) and the dictionary's longest code: every block by k_dec_write_wave
+                      bool strips = false);  // ... by its instantiation for streams with many symbols per subsequence (quarters that overflow the stage walk once, into strips)
 
 }  // namespace et

@@ -660,6 +660,41 @@ struct ChainWalk {
 };
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
+// MODE 3 of walk_write_chain: a lane's strip -- c <= 66 bytes at LDS address `at` (4-byte aligned) -- to dst, wherever that lies
+// (gfx950 takes unaligned global stores; the pieces are 16, 8, 4, 2, 1 bytes and never reach past dst + c: behind it lies the next lane's output).
+__device__ __forceinline__ void strip_flush(uint32_t at, uint32_t c, uint8_t *dst) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16_;
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    uint32_t o = 0;
+    for (; o + 16 <= c; o += 16) {
+        u32x4_ v;
+        v.x = *reinterpret_cast<const lds_u32_ *>(static_cast<uintptr_t>(at + o));
+        v.y = *reinterpret_cast<const lds_u32_ *>(static_cast<uintptr_t>(at + o + 4));
+        v.z = *reinterpret_cast<const lds_u32_ *>(static_cast<uintptr_t>(at + o + 8));
+        v.w = *reinterpret_cast<const lds_u32_ *>(static_cast<uintptr_t>(at + o + 12));
+        __builtin_memcpy(dst + o, &v, 16);
+    }
+    if (c & 8u) {
+        uint2 v;
+        v.x = *reinterpret_cast<const lds_u32_ *>(static_cast<uintptr_t>(at + o));
+        v.y = *reinterpret_cast<const lds_u32_ *>(static_cast<uintptr_t>(at + o + 4));
+        __builtin_memcpy(dst + o, &v, 8);
+        o += 8;
+    }
+    if (c & 4u) {
+        const uint32_t v = *reinterpret_cast<const lds_u32_ *>(static_cast<uintptr_t>(at + o));
+        __builtin_memcpy(dst + o, &v, 4);
+        o += 4;
+    }
+    if (c & 2u) {
+        const uint16_t v = *reinterpret_cast<const lds_u16_ *>(static_cast<uintptr_t>(at + o));
+        __builtin_memcpy(dst + o, &v, 2);
+        o += 2;
+    }
+    if (c & 1u) dst[o] = *reinterpret_cast<const lds_u8 *>(static_cast<uintptr_t>(at + o));
+}
+
 // MODE 1: positions are LDS addresses - 1 (the whole block fits the stage).  Words whose positions lie 64 or more
 // bits before the subsequence's end (32 or more when no code is 32 bits long) use the FAST step: both symbol bytes stored behind one another, whatever the
 // entry holds.  After a one-symbol entry the second slot holds a stray byte, after a no-symbol entry both do -- the
@@ -671,7 +706,8 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // overflow the stage or the declared symbol count: conditional stores throughout).
 template <int MODE>
 __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *smem8, const uint32_t (&W)[RW_WORDS], uint32_t start_rel, uint32_t pos0,
-                                                 uint32_t lo, uint32_t hi, uint32_t stage_off) {
+                                                 uint32_t lo, uint32_t hi, uint32_t stage_off, uint8_t *gdst = nullptr) {
+    constexpr bool M1 = MODE == 1 || MODE == 3;  // MODE 3: as MODE 1, into the lane's own strip, which leaves for gdst every two words (below)
     uint32_t X = (pos0 << 10) | (64 - start_rel), H = cw.root_h;
     uint2 e;
 #define CH_G (X & 1023u)
@@ -706,7 +742,7 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
         const uint32_t p0_ = X >> 10;                                                       \
         CH_ADV;                                                                             \
         const uint32_t p1_ = X >> 10;                                                       \
-        if (MODE == 1) {                                                                    \
+        if (M1) {                                                                           \
             /* second symbol first: at p0 + 1 for two symbols, else at p0, where the first (or, for none, a later one) overwrites it */ \
             CH_PUT1(p1_ - 1u + (p1_ == p0_ ? 1u : 0u), e.y >> 16);                          \
             CH_PUT1(p0_, e.x >> 16);                                                        \
@@ -721,7 +757,7 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
         CH_READ(hi_, lo_)                            \
         const uint32_t lf_ = e.x >> 24;              \
         if (lf_) {                                   \
-            if (MODE == 1) CH_PUT1(X >> 10, e.x >> 16); \
+            if (M1) CH_PUT1(X >> 10, e.x >> 16);        \
             else CH_PUT2(X >> 10, e.x >> 16)         \
             X += (1u << 10) - lf_;                   \
             H = cw.root_h;                           \
@@ -732,24 +768,36 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
     }
 #define CH_WORD_FAST(hi_, lo_)                        \
     while (CH_G >= 64u) {                             \
-        if (MODE == 1) CH_STEP_FAST(hi_, lo_)         \
+        if (M1) CH_STEP_FAST(hi_, lo_)                \
         else CH_STEP_SAFE(hi_, lo_)                   \
     }                                                 \
     X += 32;
+// MODE 3: two words hold at most 64 codewords; what they left in the strip goes to its place in the output and the strip begins anew
+#define CH_FLUSH()                                                              \
+    if (MODE == 3) {                                                            \
+        const uint32_t c_ = (X >> 10) - pos0;                                   \
+        strip_flush(pos0 + 1u, c_, gdst);                                       \
+        gdst += c_;                                                             \
+        X = (X & 1023u) | (pos0 << 10);                                         \
+    }
     CH_WORD_FAST(W[3], W[4])  // only lanes that start at bit 0
     CH_WORD_FAST(W[4], W[5])
+    CH_FLUSH()
     CH_WORD_FAST(W[5], W[6])
     CH_WORD_FAST(W[6], W[7])
+    CH_FLUSH()
     CH_WORD_FAST(W[7], W[8])
     CH_WORD_FAST(W[8], W[9])
+    CH_FLUSH()
     CH_WORD_FAST(W[9], W[10])
     // positions 193..224: a 32-bit code that begins at 224 is the lane's last, so with such codes about this word is SAFE
-    if (MODE == 1 && !cw.has_len32) {
+    if (M1 && !cw.has_len32) {
         while (CH_G >= 64u) CH_STEP_FAST(W[10], W[11])
     } else {
         while (CH_G >= 64u) CH_STEP_SAFE(W[10], W[11])
     }
     X += 32;
+    CH_FLUSH()
     // the last word: whole-index steps while the lookup's index bits all lie inside the subsequence, then one codeword at a time
     while (CH_G + (H >> 24) >= 96u) CH_STEP_SAFE(W[11], W[12])
     for (uint32_t k = 0; k < 40 && (CH_G > 64u || (CH_G == 64u && CH_MID)); ++k) CH_STEP_ONE(W[11], W[12])
@@ -758,6 +806,8 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
         X += 32;
         for (uint32_t k = 0; k < 40 && CH_MID; ++k) CH_STEP_ONE(W[12], 0u)
     }
+    CH_FLUSH()
+#undef CH_FLUSH
 #undef CH_WORD_FAST
 #undef CH_STEP_ONE
 #undef CH_STEP_SAFE
@@ -799,7 +849,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return __builtin_amdg
 #else
 #define ET_PROBE_ONE_STATE_COND
 #endif
-template <int WAVES>
+// STRIPS (a second instantiation, for streams with more than ~70 symbols per 256-bit subsequence -- a dominant symbol with a 1- or 2-bit
+// codeword, alphabets of a few symbols): a quarter whose output does not fit the stage is not walked once per 4 KiB window of its
+// output (3-4 times on such streams) but ONCE, every lane into a strip of its own (WS_STRIDE bytes of what is the stage otherwise),
+// and the strips leave for their places in the output every two stream words (walk_write_chain<3>): 64-byte pieces instead of
+// 16-byte chunks of a contiguous stage, but a third or a quarter of the lookups.  The text kernel is the instantiation without.
+constexpr uint32_t WS_STRIDE = 68;                 // a strip: the <= 64 codewords of two words + the two stray bytes of a fast step, a multiple of 4
+constexpr uint32_t WS_ALLOC = 64 * WS_STRIDE;      // (>= WV_STAGE_ALLOC: one-window quarters stage as ever)
+template <int WAVES, bool STRIPS = false>
 __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *__restrict__ words, uint64_t n_bytes, uint32_t n_blocks,
                                                               const uint2 *__restrict__ chain, uint32_t n_entries,
                                                               const uint32_t *__restrict__ sub_state, const unsigned long long *__restrict__ blk_off,
@@ -810,7 +867,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
     uint2 *tab = reinterpret_cast<uint2 *>(dec_smem_raw);
     const uint32_t tab_bytes = (n_entries * 8u + 15u) & ~15u;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t stage_off = tab_bytes + wv * WV_STAGE_ALLOC;
+    const uint32_t stage_off = tab_bytes + wv * (STRIPS ? WS_ALLOC : WV_STAGE_ALLOC);
     uint8_t *smem8 = reinterpret_cast<uint8_t *>(dec_smem_raw);
     uint8_t *stage = smem8 + stage_off;
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8 *)dec_smem_raw));
@@ -945,7 +1002,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
         WV_LDS_ORDER()                                                                                     \
     }
             uint32_t win = 0;
-            if (span) {
+            bool strips_unit = false;
+            if (STRIPS) strips_unit = span && !one_window && !this_edge && n_out == wave_total;  // (wavefront-uniform)
+            if (strips_unit) {
+                if (count) walk_write_chain<3>(cw, smem8, W, start, lds_stage + static_cast<uint32_t>(lane) * WS_STRIDE - 1u, 0, 0, 0, out + ow + my_off);
+                WV_LDS_ORDER()
+            } else if (span) {
                 for (;; win += WV_STAGE) {
                     const uint32_t win_hi = min(win + WV_STAGE, span);
                     WV_WINDOW_WALK(win, win_hi)
@@ -954,7 +1016,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
                 }
             }
             WV_TAKE()
-            if (span) WV_WINDOW_STORE(win, span)
+            if (span && !strips_unit) WV_WINDOW_STORE(win, span)
 #undef WV_WINDOW_STORE
 #undef WV_LDS_ORDER
 #undef WV_WINDOW_WALK
@@ -1031,7 +1093,7 @@ void launch_dec_scan(hipStream_t stream, const uint32_t *blk_count, uint32_t n_b
 void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_bytes, uint64_t n_subs, const DecodeTables &tb,
                       const uint32_t *sub_state,
                       const unsigned long long *blk_off, uint64_t n_symbols, uint8_t *out, uint32_t *ticket, const SideLane *side, bool ticket_is_zero,
-                      const uint32_t *void_flags, KernelEvents ev, const uint64_t *chain, uint32_t n_chain, uint32_t chain_max_len) {
+                      const uint32_t *void_flags, KernelEvents ev, const uint64_t *chain, uint32_t n_chain, uint32_t chain_max_len, bool strips) {
     const uint32_t n_blocks = static_cast<uint32_t>((n_subs + BLOCK - 1) / BLOCK);
     if (chain) {  // every block, one launch, no side lane, no ticket; `tb` is not looked at
         // 8 wavefronts per workgroup share the tables (17 KiB) beside their 4 KiB stages: 3 workgroups = 24 wavefronts per CU
@@ -1045,6 +1107,11 @@ void launch_dec_write(hipStream_t stream, const uint32_t *words, uint64_t n_byte
         if (smem_wave < 84u * 1024u) smem_wave = 84u * 1024u;  // more than half the LDS: one workgroup per CU, as beside a 47 KiB tree table
 #endif
         const uint32_t n_units = (n_blocks * 4 + WAVES - 1) / WAVES;
+        if (strips) {  // (the caller's estimate from the header: many symbols per subsequence)
+            const size_t smem_strips = ((static_cast<size_t>(n_chain) * 8 + 15) & ~static_cast<size_t>(15)) + WAVES * WS_ALLOC;
+            ET_LAUNCH_TIMED((k_dec_write_wave<WAVES, true>), dim3(decode_grid(k_dec_write_wave<WAVES, true>, smem_strips, n_units, true, 64 * WAVES)), dim3(64 * WAVES), smem_strips, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, void_flags, n_subs, chain_max_len);
+            return;
+        }
         ET_LAUNCH_TIMED(k_dec_write_wave<WAVES>, dim3(decode_grid(k_dec_write_wave<WAVES>, smem_wave, n_units, true, 64 * WAVES)), dim3(64 * WAVES), smem_wave, stream, ev, words, n_bytes, n_blocks, reinterpret_cast<const uint2 *>(chain), n_chain, sub_state, blk_off, n_symbols, out, void_flags, n_subs, chain_max_len);
         return;
     }

@@ -64,7 +64,7 @@ typedef struct et_timings {
     float sync_ms;      /* decode: everything in front of the write kernel (sweeps, verification, scan) */
     float total_ms;     /* begin of the first large kernel to the end of the last */
     uint32_t sync_iters;/* decode: synchronisation launches */
-    uint32_t reserved;  /* decode: bit 0 = the exhaustive synchronisation path ran, bit 1 = the sweeps ran as a tree walk, bit 2 = the write pass used the chained tables, bit 3 = synchronised (and, unless switched off, written) by rows: a complete code of 7- and 8-bit codewords, et_row_code, bit 4 = a fixed-length code (2^L codewords of L bits): decoded by arithmetic, no synchronisation (csrc/et_rowsync.h, k_fixed_write) */
+    uint32_t reserved;  /* decode: bit 0 = the exhaustive synchronisation path ran, bit 1 = the sweeps ran as a tree walk, bit 2 = the write pass used the chained tables, bit 3 = synchronised (and, unless switched off, written) by rows: a complete code of 7- and 8-bit codewords, et_row_code, bit 4 = a fixed-length code (2^L codewords of L bits): decoded by arithmetic, no synchronisation (csrc/et_rowsync.h, k_fixed_write), bit 5 = the write pass ran as its instantiation for streams with more than 128 symbols per 256-bit subsequence (quarters that overflow the stage walk once, into strips) */
     float sync_first_ms;/* decode: the first synchronisation sweep alone (k_dec_sync<first>) */
     uint32_t pad_;
 } et_timings;

@@ -26,7 +26,7 @@ def main():
         if trial % 97 == 0:
             ctx.enable_timing(trial % 2 == 0)  # both launch flavours: with and without kernel-carried events
         n = int(rng.integers(20_000, max_bytes))
-        src = int(rng.integers(0, 5))
+        src = int(rng.integers(0, 6))
         if src == 4:  # flat alphabets of 128 .. 255 symbols: complete codes of 7 and 8 bits -- the row walk (csrc/et_rowsync.hip)
             k = int(rng.integers(128, 256)) if rng.integers(0, 8) else 128
             if rng.integers(0, 4) == 0:  # ... and fixed-length codes: 4 .. 64 symbols (k_fixed_write)
@@ -34,6 +34,9 @@ def main():
             vals = (np.arange(k) + int(rng.integers(0, 257 - k))).astype(np.uint8)
             text = np.tile(vals, n // k + 1)[:n]
             rng.shuffle(text)
+        elif src == 5:  # one dominant value (1- or 2-bit codeword) among 2 .. 254 others: > 128 symbols per subsequence -- the write pass's strips
+            text = rng.integers(1, 2 + int(rng.integers(2, 254)), size=n).astype(np.uint8)
+            text[rng.random(n) < float(rng.choice([0.9, 0.95, 0.99, 0.999]))] = 0
         elif src == 0:
             text = corpus.text_like(n, seed * 100_000 + trial)
         elif src == 1:

@@ -119,7 +119,7 @@ def check_occupancy(md):
     def of(part):
         return next(v for k, v in md.items() if part in k)
 
-    k1, k4, d3 = of("k_hist_tiles"), of("k_encode_tilesILj4096"), of("k_dec_write_waveILi8")
+    k1, k4, d3 = of("k_hist_tiles"), of("k_encode_tilesILj4096"), of("k_dec_write_waveILi8ELb0")
     return [("K1: 32 KiB of counters, <= 64 VGPRs (4 workgroups of 512 threads per CU)", k1["lds"] == 32768 and k1["vgpr_count"] <= 64, str(k1)),
             ("K4: <= 64 VGPRs and an 18 KiB ring + table (8 workgroups per CU)", k4["vgpr_count"] <= 64 and k4["lds"] <= 20480 and k4["sgpr_spill_count"] == 0, str(k4)),
             ("D3: <= 64 VGPRs, nothing spilled (3 workgroups of 8 wavefronts per CU beside its tables)", d3["vgpr_count"] <= 64 and d3["vgpr_spill_count"] == 0 and d3["sgpr_spill_count"] == 0, str(d3))]
@@ -131,7 +131,7 @@ def run_checks(paths):
         md.update(metadata(p))
     res = []
     res += check_k4(function_lines(paths["et_kernels"], "k_encode_tilesILj4096"))
-    res += check_d3(function_lines(paths["et_kernels"], "k_dec_write_waveILi8"))
+    res += check_d3(function_lines(paths["et_kernels"], "k_dec_write_waveILi8ELb0"))
     res += check_d1(function_lines(paths["et_treewalk"], "k_tw_sync"), md)
     res += check_occupancy(md)
     return res
