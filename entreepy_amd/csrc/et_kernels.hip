@@ -663,6 +663,10 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // MODE 3 of walk_write_chain: a lane's strip -- c <= 66 bytes at LDS address `at` (4-byte aligned) -- to dst, wherever that lies
 // (gfx950 takes unaligned global stores; the pieces are 16, 8, 4, 2, 1 bytes and never reach past dst + c: behind it lies the next lane's output).
 __device__ __forceinline__ void strip_flush(uint32_t at, uint32_t c, uint8_t *dst) {
+#ifdef ET_PROBE_STRIPS_NO_FLUSH  // (timing probe, wrong output: what the strips' way out costs -- 0.27 -> 0.13 ms at 90 % zeros, 0.20 -> 0.13 at 97 %, 256 MiB)
+    (void)at, (void)c, (void)dst;
+    return;
+#endif
     typedef __attribute__((address_space(3))) uint32_t lds_u32_;
     typedef __attribute__((address_space(3))) uint16_t lds_u16_;
     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
