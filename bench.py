@@ -198,7 +198,7 @@ def measure_stream(torch, ctx, pipe, text, enc, dec, reps, lead, decode=True, ve
     return out
 
 
-EXTRA_WORKLOADS = ("enwik-like", "text-100M", "text-5M", "flat4-1G", "flat10-1G", "flat26-1G", "uniform255-4G", "uniform256-16G")
+EXTRA_WORKLOADS = ("enwik-like", "text-100M", "text-5M", "flat4-1G", "flat10-1G", "flat26-1G", "zeros97-1G", "uniform255-4G", "uniform256-16G")
 
 
 def run_extra_workload(name, torch, E, corpus, ctx, pipe, dev, n_headline, verify=True, reps=None):
@@ -246,6 +246,18 @@ def run_extra_workload(name, torch, E, corpus, ctx, pipe, dev, n_headline, verif
         text = uniform_bytes_torch(n, 48, 48 + k, 0x5EED0F00 + k, dev)
         what = (f"{name}: {n} B uniform over {k} byte values, seed {0x5EED0F00 + k:#x} (not a BASELINE configuration: the small flat alphabets beside configs[4]); "
                 + ("2-bit codewords only: decoded by arithmetic, no synchronisation" if k == 4 else "codes of two neighbouring lengths that settle quickly: the tree walk"))
+        reps, lead, decode = reps or 10, 10, True
+    elif name == "zeros97-1G":  # not a BASELINE configuration: a stream with one dominant value (a 1-bit codeword, ~200 symbols per 256-bit subsequence)
+        n = n_headline
+        text = uniform_bytes_torch(n, 1, 255, 0x5EED0097, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5EED0097)
+        step = 1 << 26
+        for s0 in range(0, n, step):
+            m = min(step, n - s0)
+            text[s0 : s0 + m][torch.rand(m, generator=g, device=dev) < 0.97] = 0
+        what = (f"zeros97-1G: {n} B, 97 % zero bytes, the rest uniform over 254 other values, seed 0x5EED0097 (not a BASELINE configuration: "
+                "~200 symbols per 256-bit subsequence -- the write pass's instantiation that walks a quarter once, into strips)")
         reps, lead, decode = reps or 10, 10, True
     else:
         return {"error": f"unknown workload {name}"}
