@@ -776,12 +776,18 @@ __device__ __forceinline__ void walk_write_chain(const ChainWalk cw, uint8_t *sm
         else CH_STEP_SAFE(hi_, lo_)                   \
     }                                                 \
     X += 32;
+// (timing probe, wrong output: the strips' pieces side by side and 16-byte aligned -- lane l's at 64 l of a 4 KiB row per flush -- instead of where they belong)
+#ifdef ET_PROBE_STRIPS_DENSE_DST
+#define ET_PROBE_STRIPS_STEP(c_) 4096u
+#else
+#define ET_PROBE_STRIPS_STEP(c_) (c_)
+#endif
 // MODE 3: two words hold at most 64 codewords; what they left in the strip goes to its place in the output and the strip begins anew
 #define CH_FLUSH()                                                              \
     if (MODE == 3) {                                                            \
         const uint32_t c_ = (X >> 10) - pos0;                                   \
         strip_flush(pos0 + 1u, c_, gdst);                                       \
-        gdst += c_;                                                             \
+        gdst += ET_PROBE_STRIPS_STEP(c_);                                       \
         X = (X & 1023u) | (pos0 << 10);                                         \
     }
     CH_WORD_FAST(W[3], W[4])  // only lanes that start at bit 0
@@ -1009,7 +1015,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_dec_write_wave(const uint32_t *_
             bool strips_unit = false;
             if (STRIPS) strips_unit = span && !one_window && !this_edge && n_out == wave_total;  // (wavefront-uniform)
             if (strips_unit) {
-                if (count) walk_write_chain<3>(cw, smem8, W, start, lds_stage + static_cast<uint32_t>(lane) * WS_STRIDE - 1u, 0, 0, 0, out + ow + my_off);
+                if (count) walk_write_chain<3>(cw, smem8, W, start, lds_stage + static_cast<uint32_t>(lane) * WS_STRIDE - 1u, 0, 0, 0,
+#ifdef ET_PROBE_STRIPS_DENSE_DST
+                                                     out + (ow & ~static_cast<uint64_t>(15)) + static_cast<uint32_t>(lane) * 64u);
+#else
+                                                     out + ow + my_off);
+#endif
                 WV_LDS_ORDER()
             } else if (span) {
                 for (;; win += WV_STAGE) {
